@@ -1,0 +1,140 @@
+/* pyflow_hip.h -- C ABI of libpyflow_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary of the MI355X-native pyramidal flow-matching sampler.  The reference
+ * (jy0205/Pyramid-Flow) has NO native/FFI layer: its operators are torch calls inside Python
+ * classes.  Each entry point below therefore replaces a *call site* of the reference, cited as
+ * file:line relative to the reference root.  The Python host (pyramid-flow_amd/) binds these with
+ * ctypes and keeps the reference's class/method signatures on top.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless said otherwise;
+ *   - every call is asynchronous on the hipStream_t passed in, performs no allocation and no
+ *     synchronisation; the caller owns all memory;
+ *   - return 0 on success, negative on error; pf_last_error() returns a thread-local message;
+ *   - bf16 tensors are raw uint16 storage; "f32" pointers are float.
+ */
+#ifndef PYFLOW_HIP_H
+#define PYFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* pf_stream_t; /* == hipStream_t */
+
+const char* pf_last_error(void);
+int pf_version(void);
+
+/* ------------------------------------------------------------------ GEMM (nn.Linear) ------------
+ * C[b] = epi( A[b] (M x K, row stride lda) . W^T (W is N x K, row stride ldw, nn.Linear layout) )
+ * Replaces: attn.to_q/to_k/to_v/add_*_proj (flux_block.py:756-758, 816-835), to_out/to_add_out
+ * (:868-872), FeedForward (:42-100, GELU-tanh), proj_mlp/proj_out of the single blocks (:921-937),
+ * x_embedder / context_embedder / proj_out (modeling_pyramid_flux.py:401, 290, 539).
+ * flags: PF_GEMM_GATE_RES   C = res + gate[b, n] * (acc + bias[n])   (gate NULL -> 1)
+ *        PF_GEMM_OUT_F32    C is float instead of bf16
+ * gelu_from: columns n >= gelu_from get GELU(tanh) after the bias (-1 = none).
+ * Constraints: N % 128 == 0, K % 64 == 0, lda/ldw/ldc % 8 == 0.  M arbitrary. */
+#define PF_GEMM_GATE_RES 1
+#define PF_GEMM_OUT_F32 2
+typedef struct {
+    const void* A; const void* W; void* C;
+    const float* bias;      /* [N] or NULL */
+    const void* res;        /* bf16, same indexing as C with ldr / strideR */
+    const float* gate;      /* [batch, gate_stride] */
+    int M, N, K, lda, ldw, ldc, ldr;
+    long long strideA, strideC, strideR;
+    int gate_stride, batch, gelu_from, flags;
+} pf_gemm_desc;
+int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
+
+/* ------------------------------------------------------------------ CausalConv3d ----------------
+ * Implicit-GEMM convolution over a channels-last, zero-padded input (replaces CausalConv3d.forward,
+ * video_vae/modeling_causal_conv.py:116-146, incl. the chunk cache: the caller keeps the two
+ * previous frames in the first two temporal slots of X).  Rows = output pixels (t,h,w), K =
+ * kt*kh*kw*Cin, N = filters (padded to 128).  Input element for pixel (t,h,w), tap (dt,dh,dw),
+ * channel c:  X[in_base_off + (((t+dt)*Hp + h+dh)*Wp + w+dw)*Cin + c].
+ * Output column n = g*Cg + c (g = (pt*sh + ph)*sw + pw: depth-to-time / pixel-shuffle group, the
+ * host permutes filter rows accordingly; modeling_resnet.py:609-617, 716-729) is stored at
+ * Y[out_base_off + (((t*st+pt)*Hop + h*sh+ph)*Wop + w*sw+pw)*Cout_pitch + c]; columns >= n_valid
+ * are dropped.  flags PF_GEMM_GATE_RES adds res at the same output offset (resnet shortcut add,
+ * modeling_resnet.py:148); out_scale multiplies the result (1/output_scale_factor). */
+typedef struct {
+    const void* X; const void* W; void* Y; const float* bias; const void* res;
+    int T, H, W_;            /* output pixel grid */
+    int Hp, Wp, Cin, kt, kh, kw;
+    long long in_base_off;
+    int N, n_valid;
+    int st, sh, sw, Cg, Hop, Wop, Cout_pitch;
+    long long out_base_off;
+    int flags; float out_scale;
+} pf_conv_desc;
+int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
+
+
+/* ------------------------------------------------------------------ attention --------------------
+ * O = softmax(Q K^T * scale + mask) V, head_dim 64, over the joint [text | image] sequence of one
+ * pyramid stage.  Replaces F.scaled_dot_product_attention + the [B,1,L,L] bool mask
+ * (flux_block.py:361-365, 597-599; modeling_pyramid_flux.py:318-350).  The mask is implicit: query
+ * row i may see keys j in [a_lo[i], a_hi[i]) for j < Lt (text part) and keys Lt <= j < b_hi[i]
+ * (image part).  tile_kv_end[b][qt] = max b_hi over the 128-row q tile qt (and >= Lt if any text key
+ * is visible).  Q/K are token-major (row stride ldq/ldk, head h at column h*64); Vt is the image
+ * written by pf_v_transpose: [B][H][64][Lp], keys permuted inside groups of 16.  O may alias Q. */
+typedef struct {
+    const void* Q; const void* K; const void* Vt; void* O;
+    int ldq, ldk, ldo;
+    long long strideQ, strideK, strideO, strideVt_b, strideVt_h;
+    int B, H, L, Lp, Lt;
+    const int* a_lo; const int* a_hi; const int* b_hi; /* [B][L] */
+    const int* tile_kv_end;                            /* [B][ceil(L/128)] */
+    float scale;
+} pf_attn_desc;
+int pf_attention_bf16(const pf_attn_desc* d, pf_stream_t stream);
+int pf_v_transpose(const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b, long long strideVt_h,
+                   int B, int H, int L, int Lp, pf_stream_t stream);
+
+/* ------------------------------------------------------------------ token-wise ops ---------------
+ * pf_ln_modulate: y = LN(x; no affine, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero/Single/
+ *   Continuous modeling_normalization.py:107-249 and norm2/norm2_context flux_block.py:1022-1036).
+ *   x,y bf16 [B][rows_per_batch][D] with batch strides / leading dims in elements; shift/scale fp32
+ *   [B][mod_bstride]. */
+int pf_ln_modulate(const void* x, void* y, const float* shift, const float* scale, int D, int B, int rows_per_batch,
+                   long long x_bstride, long long y_bstride, int ldx, int ldy, int mod_bstride, float eps,
+                   pf_stream_t stream);
+/* pf_qk_norm_rope: in place on a fused projection buffer [B][L][ld]: q at column q_off, k at k_off
+ *   (H heads x 64).  RMSNorm(eps) with fp32 weights (text rows < Lt use *_txt, NULL = same as image:
+ *   norm_added_q/k vs norm_q/k, flux_block.py:846-850, 772-775), then RoPE with the per-token table
+ *   rope[L][32][cos,sin] (flux_block.py:34-39). */
+int pf_qk_norm_rope(void* qkv, int ld, long long bstride, int q_off, int k_off, const float* wq_img,
+                    const float* wk_img, const float* wq_txt, const float* wk_txt, const float* rope, int B, int L,
+                    int Lt, int H, float eps, pf_stream_t stream);
+/* pf_gemv_f32: y[b][0:N] (+)= W[N][K](bf16) . act(x[b][0:K]) + bias, 1 <= B <= 4, act = SiLU if silu_in
+ *   (time_text_embed and every AdaLN linear: modeling_embedding.py:185-200, modeling_normalization.py:160,227,111) */
+int pf_gemv_f32(const void* W, int ldw, const float* bias, const float* x, int ldx, float* y, int ldy, int N, int K,
+                int B, int silu_in, int accumulate, pf_stream_t stream);
+/* pf_timestep_embed: out[b][0:dim] = [cos(t_b f_k) | sin(t_b f_k)], f_k = exp(-ln(1e4) k/(dim/2));
+ *   t_host is a HOST array of B floats (passed by value into the launch). modeling_embedding.py:11-62 */
+int pf_timestep_embed(float* out, int ld, int B, const float* t_host, int dim, pf_stream_t stream);
+/* pf_patchify: latent clip [C][T][H][W] (fp32 or bf16) -> ncopies x tokens[(t h w)][(p1 p2 c)] bf16
+ *   (modeling_pyramid_flux.py:286-287; CFG duplicates the clip, pipeline.py:747) */
+int pf_patchify(const void* x, int x_is_f32, void* tok, int C, int T, int H, int W, int ld, long long bstride,
+                int ncopies, pf_stream_t stream);
+/* pf_cfg_euler_step: v fp32 tokens [2][n][ld] of the current frame -> unpatchify, CFG combine with
+ *   `guidance`, x += dsigma * v on the fp32 latent x[C][H][W] (pipeline.py:771-784,
+ *   scheduling_flow_matching.py:278-286).  round_bf16 reproduces the reference bf16 rounding points. */
+int pf_cfg_euler_step(const float* v, long long vb_stride, int ld, float* x, int C, int H, int W, float guidance,
+                      int use_cfg, float dsigma, int round_bf16, pf_stream_t stream);
+int pf_copy_rows(const void* src, void* dst, int rows, int D, int ld_src, int ld_dst, long long src_bstride,
+                 long long dst_bstride, int B, pf_stream_t stream);
+/* pf_renoise_upsample: xout = alpha * nearest_up2(xin) + beta * noise   (pipeline.py:729-743) */
+int pf_renoise_upsample(const float* xin, const float* noise, float* xout, int C, int H, int W, float alpha,
+                        float beta, int round_bf16, pf_stream_t stream);
+/* pf_avgpool2: 2x2 mean * mul == F.interpolate(bilinear, 1/2) (pipeline.py:565, 1116) */
+int pf_avgpool2(const float* xin, float* xout, long long planes, int H, int W, float mul, int round_bf16,
+                pf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

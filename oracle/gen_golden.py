@@ -1,0 +1,131 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.pt by running the UNMODIFIED reference
+(/root/reference, CPU fp32) on seeded tiny models.  Run in the dev container:
+    python -m oracle.gen_golden
+Fixtures are small (bf16-rounded weights stored as bf16) and committed; the GPU box has no reference.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+
+from oracle import ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+NEG = ("cartoon style, worst quality, low quality, blurry, absolute black, absolute white, low res, extra limbs, "
+       "extra digits, misplaced objects, mutated anatomy, monochrome, horror")
+
+
+from pyflow_hip import synth  # noqa: E402  (host-side shape tables only; no HIP involved)
+
+DIT_SEED, VAE_SEED = 3, 5
+VAE_CFG_REF = dict(encoder_out_channels=16, decoder_in_channels=16,
+                   encoder_block_out_channels=(32, 32, 64, 64), decoder_block_out_channels=(32, 32, 64, 64),
+                   encoder_layers_per_block=(1, 1, 1, 1), decoder_layers_per_block=(2, 2, 2, 2))
+
+
+def synth_dit_sd():
+    sd = synth.random_state_dict(synth.flux_param_shapes(synth.TINY_FLUX), seed=DIT_SEED, std=0.05, lively=True)
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def synth_vae_sd():
+    sd = synth.random_state_dict(synth.vae_decoder_param_shapes(synth.TINY_VAE), seed=VAE_SEED, std=0.05, lively=True)
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def build_dit():
+    """reference module carrying the seeded synthetic weights (weights are re-derivable from the seed,
+    so fixtures only store inputs and outputs)."""
+    ref = rh.shims.load_reference()
+    m = ref.PyramidFluxTransformer(**synth.TINY_FLUX).eval()
+    m.load_state_dict(synth_dit_sd(), strict=True)
+    return m
+
+
+def build_vae():
+    ref = rh.shims.load_reference()
+    v = ref.CausalVideoVAE(**VAE_CFG_REF).eval()
+    missing, unexpected = v.load_state_dict(synth_vae_sd(), strict=False)
+    assert not unexpected and all(k.startswith(("encoder.", "quant_conv.")) for k in missing)
+    return v
+
+
+def flux_forward_fixture():
+    dit = build_dit()
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    shapes = [(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)]
+    clips = [torch.randn(B, 16, *s, generator=g).to(torch.bfloat16).float() for s in shapes]
+    enc = torch.randn(B, 16, 32, generator=g).to(torch.bfloat16).float()
+    mask = torch.zeros(B, 16, dtype=torch.long)
+    mask[0, :5] = 1
+    mask[1, :12] = 1
+    pooled = torch.randn(B, 16, generator=g)
+    t = torch.tensor([704.0, 704.0])
+    with torch.no_grad():
+        out = dit(sample=[clips], encoder_hidden_states=enc, encoder_attention_mask=mask,
+                  pooled_projections=pooled, timestep_ratio=t)[0]
+    torch.save(dict(cfg=synth.TINY_FLUX, weight_seed=DIT_SEED,
+                    clips=clips, enc=enc, mask=mask, pooled=pooled, timestep=t, out=out),
+               os.path.join(OUT, "flux_tiny_forward.pt"))
+
+
+def vae_fixture():
+    vae = build_vae()
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(1, 16, 3, 6, 10, generator=g)
+    with torch.no_grad():
+        out = vae.decode(z, temporal_chunk=True, window_size=1).sample
+        vae.enable_tiling()
+        out_t = vae.decode(z, temporal_chunk=True, window_size=1, tile_sample_min_size=32).sample
+    torch.save(dict(cfg=synth.TINY_VAE, weight_seed=VAE_SEED, z=z, out=out.to(torch.bfloat16),
+                    out_tiled32=out_t.to(torch.bfloat16)), os.path.join(OUT, "vae_tiny_decode.pt"))
+
+
+def generate_fixture():
+    dit = build_dit()
+    vae = build_vae()
+    pipe = rh.build_ref_pipeline(dit, vae)
+    rh.patch_block_noise(pipe, rh.NoiseStream(1))
+    H, W, temp = 64, 128, 3
+    with torch.no_grad():
+        lat = pipe.generate(prompt="a cat", height=H, width=W, temp=temp, num_inference_steps=[3, 3, 3],
+                            video_num_inference_steps=[2, 2, 2], guidance_scale=7.0, video_guidance_scale=5.0,
+                            generator=torch.Generator().manual_seed(0), output_type="latent")
+    te = pipe.text_encoder
+    pe, pm, pp = te("a cat, hyper quality, Ultra HD, 8K", None)
+    ne, nm, npool = te(NEG, None)
+    torch.save(dict(dit_cfg=synth.TINY_FLUX, vae_cfg=synth.TINY_VAE, dit_weight_seed=DIT_SEED, vae_weight_seed=VAE_SEED,
+                    prompt_embeds=torch.cat([ne, pe]), prompt_mask=torch.cat([nm, pm]), pooled=torch.cat([npool, pp]),
+                    height=H, width=W, temp=temp, steps=[3, 3, 3], video_steps=[2, 2, 2], guidance=7.0,
+                    video_guidance=5.0, latent_seed=0, noise_seed=1, latents=lat),
+               os.path.join(OUT, "generate_tiny_latents.pt"))
+
+
+def scheduler_fixture():
+    ref = rh.shims.load_reference()
+    out = {}
+    for name, kw in (("default", {}), ("one_stage", dict(stages=1, stage_range=[0, 1]))):
+        s = ref.PyramidFlowMatchEulerDiscreteScheduler(**kw)
+        rec = dict(start=dict(s.start_sigmas), end=dict(s.end_sigmas), ori=dict(s.ori_start_sigmas),
+                   ratios=dict(s.timestep_ratios), tables={})
+        for st in range(s.config.stages):
+            for n in (10, 20):
+                s.set_timesteps(n, st)
+                rec["tables"][(st, n)] = (s.timesteps.clone(), s.sigmas.clone())
+        out[name] = rec
+    torch.save(out, os.path.join(OUT, "scheduler_tables.pt"))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    flux_forward_fixture()
+    vae_fixture()
+    generate_fixture()
+    scheduler_fixture()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

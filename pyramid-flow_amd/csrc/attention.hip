@@ -1,0 +1,280 @@
+// Joint text-video flash attention with the reference's block-causal temporal mask, head_dim 64.
+//
+// Replaces F.scaled_dot_product_attention(q, k, v, attn_mask=[B,1,L,L] bool) of
+// VarlenSelfAttentionWithT5Mask / VarlenSelfAttnSingle (flux_block.py:328-376, 568-606) and the
+// mask construction of merge_input (modeling_pyramid_flux.py:318-350).  The L x L boolean mask
+// is never materialised: the reference mask  (id_i == id_j) & (t_i >= t_j)  reduces, for the
+// time-ordered sequence [text | history clips | current frame], to two key intervals per query
+// row i:   keys in [a_lo_i, a_hi_i)  (text part, j < Lt)   U   keys in [Lt, b_hi_i)  (image part),
+// which the host derives once per (unit, stage).  KV tiles beyond a q-tile's largest b_hi are
+// never visited; waves whose 32 rows cannot see a tile skip its MFMAs.
+//
+// Structure: 128 q rows per workgroup (4 waves x 32 rows), KV tiles of 64 keys.  S^T = K.Q^T is
+// computed "swapped" so one lane owns one q row (lane&31) and 16 keys per 32x32 tile: row max /
+// sum are lane-local plus ONE cross-half exchange; P feeds the PV MFMA straight from registers
+// because the contraction-slot -> key permutation of the C layout is mirrored in the V^T image
+// (pf_v_transpose writes keys permuted within groups of 16).  K and V^T tiles arrive by LDS-DMA
+// with source-side XOR swizzle, double-buffered, one barrier per KV tile.
+#include "common.h"
+#include "pyflow_hip.h"
+
+namespace {
+
+constexpr int QB = 128, KB = 64, HD = 64;
+constexpr int KTILE = KB * HD * 2;     // 8 KiB
+constexpr int ABUF = 2 * KTILE;        // K + V^T
+constexpr float NEG = -1.0e30f;
+
+struct AArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+    int ldq, ldk, ldo;
+    long long sQ, sK, sO, sVb, sVh;
+    int Lp, L, H, B, Lt, nqt;
+    const int* a_lo; const int* a_hi; const int* b_hi;
+    const int* tile_kv_end;
+    float sc;   // softmax scale * log2(e)
+};
+
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = p.nqt * p.H * p.B;
+    int t = xcd_remap(blockIdx.x, nwg);
+    const int bh = t / p.nqt;
+    const int qt = p.nqt - 1 - (t - bh * p.nqt);      // heaviest (latest) q tiles first
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * QB;
+    const int frow = lane & 31, hi = lane >> 5, swz = (lane >> 1) & 7;
+
+    // ---- this lane's query row ----
+    const int qrow = q0 + wid * 32 + frow;
+    const bool qvalid = qrow < p.L;
+    const int qr = qvalid ? qrow : p.L - 1;
+    const bf16_t* qp = p.Q + (long long)b * p.sQ + (long long)qr * p.ldq + h * HD + hi * 8;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
+    int alo = 0, ahi = 0, bhi = 0;
+    if (qvalid) {
+        alo = p.a_lo[(long long)b * p.L + qrow];
+        ahi = p.a_hi[(long long)b * p.L + qrow];
+        bhi = p.b_hi[(long long)b * p.L + qrow];
+    }
+    int wmax = bhi, wmin = qvalid ? bhi : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        wmax = max(wmax, __shfl_xor(wmax, o));
+        wmin = min(wmin, __shfl_xor(wmin, o));
+    }
+    const int kv_end = p.tile_kv_end[b * p.nqt + qt];
+    const int ntiles = (kv_end + KB - 1) / KB;
+
+    // ---- DMA sources: wave owns pieces i = wid*2 + j (rows 8i..8i+7) of the K and V^T tiles ----
+    const bf16_t* kbase = p.K + (long long)b * p.sK + h * HD;
+    const bf16_t* vbase = p.Vt + (long long)b * p.sVb + (long long)h * p.sVh;
+    int prow[2], pc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = wid * 2 + j;
+        prow[j] = 8 * i + (lane >> 3);
+        pc[j] = ((lane & 7) ^ (((i & 1) << 2) + (lane >> 4))) * 8;
+    }
+    auto issue = [&](int jt, int buf) {
+        const int j0 = jt * KB;
+        char* base = smem + buf * ABUF + wid * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int key = j0 + prow[j];
+            key = key < p.L ? key : p.L - 1;
+            glds16(kbase + (long long)key * p.ldk + pc[j], base + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            glds16(vbase + (long long)prow[j] * p.Lp + j0 + pc[j], base + KTILE + j * 1024);
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = NEG, l = 0.f;
+
+    if (ntiles > 0) issue(0, 0);
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int buf = jt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (jt + 1 < ntiles) issue(jt + 1, buf ^ 1);
+        const int j0 = jt * KB;
+        const bool has_text = j0 < p.Lt;
+        if (!has_text && j0 >= wmax) continue;     // wave-uniform: nothing visible for these 32 rows
+        const char* sk = smem + buf * ABUF;
+        const char* sv = sk + KTILE;
+        f32x16_t s[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ((2 * ks + hi) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sk + (i * 32 + frow) * 128 + ch);
+                s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[i], 0, 0, 0);
+            }
+        }
+        const bool masked = has_text || (j0 + KB > wmin);
+        if (masked) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = j0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < p.Lt ? (key >= alo && key < ahi) : (key < bhi);
+                    s[i][r] = ok ? s[i][r] : NEG;
+                }
+        }
+        float mt = s[0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[i][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
+        const float msc = mn * p.sc;
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][r], p.sc, -msc));
+                if (masked) e = (s[i][r] == NEG) ? 0.f : e;
+                s[i][r] = e;
+                ps += e;
+            }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[g][e] = (bf16_t)s[g >> 1][8 * (g & 1) + e];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ((2 * g + hi) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8_t vf = *(const bf16x8_t*)(sv + (i * 32 + frow) * 128 + ch);
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[i], 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (qvalid) {
+        bf16_t* op = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + h * HD + 4 * hi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                u32x2_t w;
+                w[0] = pack2(o[i][4 * q4] * inv, o[i][4 * q4 + 1] * inv);
+                w[1] = pack2(o[i][4 * q4 + 2] * inv, o[i][4 * q4 + 3] * inv);
+                *(u32x2_t*)(op + i * 32 + q4 * 8) = w;
+            }
+    }
+}
+
+// V [B, L, H*64] (row stride ldv) -> V^T [B, H, 64, Lp] with keys permuted inside each group of
+// 16 (bits 2 and 3 of the key index swapped) so the PV A-operand is one ds_read_b128 per lane.
+__global__ __launch_bounds__(256) void vtrans_kernel(const bf16_t* V, bf16_t* Vt, int ldv, long long sV,
+                                                     long long sVb, long long sVh, int L, int Lp, int H) {
+    __shared__ unsigned short tile[64][66];
+    const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int j0 = kt * 64;
+    // load 64 keys x 64 d : thread -> key = tid/4 (+0), 16 d values
+    {
+        const int key = tid >> 2, dq = (tid & 3) * 16;
+        const int kk = j0 + key;
+        unsigned short vals[16];
+        if (kk < L) {
+            const u32x4_t a = *(const u32x4_t*)(V + (long long)b * sV + (long long)kk * ldv + h * 64 + dq);
+            const u32x4_t c = *(const u32x4_t*)(V + (long long)b * sV + (long long)kk * ldv + h * 64 + dq + 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vals[2 * e] = a[e] & 0xffff; vals[2 * e + 1] = a[e] >> 16;
+                vals[8 + 2 * e] = c[e] & 0xffff; vals[8 + 2 * e + 1] = c[e] >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vals[e] = 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[dq + e][key] = vals[e];
+    }
+    __syncthreads();
+    // store: thread -> d = tid/4, 16 permuted key slots
+    {
+        const int d = tid >> 2, s0 = (tid & 3) * 16;
+        unsigned short out[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int slot = e;                                  // position inside the group of 16
+            const int key = (slot & 3) | ((slot & 4) << 1) | ((slot & 8) >> 1);   // swap bits 2,3
+            out[e] = tile[d][s0 + key];
+        }
+        u32x4_t a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = out[2 * e] | ((unsigned)out[2 * e + 1] << 16);
+            c[e] = out[8 + 2 * e] | ((unsigned)out[8 + 2 * e + 1] << 16);
+        }
+        bf16_t* dst = Vt + (long long)b * sVb + (long long)h * sVh + (long long)d * Lp + j0 + s0;
+        *(u32x4_t*)dst = a;
+        *(u32x4_t*)(dst + 8) = c;
+    }
+}
+
+}  // namespace
+
+int pf_set_err(const char* m);
+
+extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
+    if (!d || !d->Q || !d->K || !d->Vt || !d->O) return pf_set_err("pf_attention_bf16: null operand");
+    if (d->L <= 0 || d->B <= 0 || d->H <= 0) return pf_set_err("pf_attention_bf16: empty problem");
+    if (d->Lp % 64 || d->Lp < d->L) return pf_set_err("pf_attention_bf16: Lp must be a multiple of 64 and >= L");
+    if ((d->ldq % 8) || (d->ldk % 8) || (d->ldo % 4)) return pf_set_err("pf_attention_bf16: bad leading dims");
+    AArgs a{};
+    a.Q = (const bf16_t*)d->Q; a.K = (const bf16_t*)d->K; a.Vt = (const bf16_t*)d->Vt; a.O = (bf16_t*)d->O;
+    a.ldq = d->ldq; a.ldk = d->ldk; a.ldo = d->ldo;
+    a.sQ = d->strideQ; a.sK = d->strideK; a.sO = d->strideO; a.sVb = d->strideVt_b; a.sVh = d->strideVt_h;
+    a.Lp = d->Lp; a.L = d->L; a.H = d->H; a.B = d->B; a.Lt = d->Lt;
+    a.nqt = (d->L + QB - 1) / QB;
+    a.a_lo = d->a_lo; a.a_hi = d->a_hi; a.b_hi = d->b_hi; a.tile_kv_end = d->tile_kv_end;
+    a.sc = d->scale * 1.4426950408889634f;
+    const int grid = a.nqt * a.H * a.B;
+    hipLaunchKernelGGL(attn_kernel, dim3(grid), dim3(256), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pf_v_transpose(const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b,
+                              long long strideVt_h, int B, int H, int L, int Lp, hipStream_t stream) {
+    if (!V || !Vt) return pf_set_err("pf_v_transpose: null operand");
+    if (Lp % 64 || Lp < L || (ldv % 8)) return pf_set_err("pf_v_transpose: bad Lp/ldv");
+    hipLaunchKernelGGL(vtrans_kernel, dim3(Lp / 64, H, B), dim3(256), 0, stream, (const bf16_t*)V, (bf16_t*)Vt,
+                       ldv, strideV, strideVt_b, strideVt_h, L, Lp, H);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));
+    return 0;
+}

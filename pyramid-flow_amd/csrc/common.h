@@ -1,0 +1,64 @@
+// Shared device helpers for the pyflow HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+#define PF_DEVICE __device__ __forceinline__
+
+// Direct global -> LDS DMA, 16 bytes per lane.  LDS destination = wave-uniform `lds_base` + lane*16
+// (the hardware adds the lane offset); the global source is per lane.
+PF_DEVICE void glds16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+PF_DEVICE float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+PF_DEVICE void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i]     = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+
+PF_DEVICE unsigned pack2(float a, float b) {
+    bf16x2_t t;
+    t[0] = (bf16_t)a;
+    t[1] = (bf16_t)b;
+    return __builtin_bit_cast(unsigned, t);
+}
+
+PF_DEVICE u32x4_t pack8(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+PF_DEVICE float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+PF_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): gives each XCD a
+// contiguous run of logical tile ids so neighbouring tiles share operand panels in one L2.
+PF_DEVICE int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,278 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )
+//
+// Serves the DiT projections (K7/K11/K13/K14 of SURVEY section 2.2: QKV, out-proj, MLP, fused
+// QKV+MLP of the single-stream blocks; reference call sites flux_block.py:756-758, 816-835,
+// 868-872, 914-942) and -- in implicit-GEMM mode -- the CausalConv3d of the VAE decoder
+// (video_vae/modeling_causal_conv.py:116-146).
+//
+// Structure: 128x128 block tile, BK = 64, 4 waves (2x2), each wave a 64x64 sub-tile as 2x2
+// v_mfma_f32_32x32x16_bf16 tiles.  Operand tiles go HBM -> LDS by direct LDS-DMA
+// (global_load_lds_dwordx4, 16 B/lane, no VGPR round trip); the LDS image is lane-linear, so the
+// bank-conflict-free XOR swizzle is applied on the per-lane SOURCE address and again on the
+// ds_read_b128 address (same involution).  Double-buffered, ONE barrier per K-step: the loads
+// of tile k+1 are issued right after the barrier that publishes tile k and fly under its MFMAs.
+// Epilogue: accumulators are staged through LDS as fp32, then every thread streams whole
+// 16-byte bf16 pieces (bias / GELU-tanh / gate*x+residual applied in fp32) -> coalesced stores.
+#include "common.h"
+#include "pyflow_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + W
+constexpr int SMEM_BYTES = 2 * BUF_BYTES;        // double buffered = 64 KiB (= fp32 128x128 epilogue stage)
+
+struct ConvGeom {            // implicit-GEMM addressing of a channels-last, spatially padded input
+    int H, W;                // output spatial size (rows of the GEMM are (t,h,w) pixels)
+    int Hp, Wp;              // padded input spatial pitch (H+2pad, W+2pad)
+    int Cin;                 // input channels (K = ntaps*Cin)
+    int kt, kh, kw;          // taps
+    long long base_off;      // element offset of tap (0,0,0) for output pixel (0,0,0)
+};
+
+struct OutMap {              // where output row m / column-group g lands
+    int mode;                // 0 = plain [M, ldc];  1 = pixel map into [To,Hop,Wop,C] with shuffles
+    int H, W;                // GEMM-row pixel grid
+    int st, sh, sw;          // upsample factors (depth-to-time, pixel shuffle)
+    int Cg;                  // channels per group (N = st*sh*sw*Cg for shuffles)
+    int Hop, Wop;            // padded output pitches
+    long long base_off;      // element offset of output pixel (0,0,0) channel 0
+    int Cout_pitch;          // channel pitch of the output buffer
+};
+
+struct Args {
+    const bf16_t* A; const bf16_t* W; void* C;
+    const float* bias; const bf16_t* res; const float* gate;
+    int M, N, K, lda, ldw, ldc, ldr;
+    long long sA, sC, sR;    // batch strides (elements)
+    int gate_stride, batch;
+    int gelu_from, flags, n_valid;
+    float out_scale;
+    ConvGeom cg; OutMap om;
+};
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int per_batch = tiles_n * tiles_m;
+    const int nwg = per_batch * p.batch;
+    int t = xcd_remap(blockIdx.x, nwg);
+    const int b = t / per_batch;
+    t -= b * per_batch;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const bf16_t* A = p.A + (long long)b * p.sA;
+    // ---- per-lane DMA source pointers: wave `wid` owns 1-KiB pieces i = wid*4 + j of each tile,
+    //      piece i = rows 8i..8i+7; lane -> row 8i + lane/8, LDS chunk c' = lane%8 holds source
+    //      chunk c = c' ^ ((row>>1)&7).
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = wid * 4 + j;
+        const int r = 8 * i + (lane >> 3);
+        const int c = (lane & 7) ^ (((i & 1) << 2) + (lane >> 4));
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;
+        if (CONV) {
+            const int hw = p.cg.H * p.cg.W;
+            const int tt = m / hw, rem = m - tt * hw;
+            const int hh = rem / p.cg.W, ww = rem - hh * p.cg.W;
+            asrc[j] = A + p.cg.base_off + (((long long)tt * p.cg.Hp + hh) * p.cg.Wp + ww) * p.cg.Cin + c * 8;
+        } else {
+            asrc[j] = A + (long long)m * p.lda + c * 8;
+        }
+        wsrc[j] = p.W + (long long)(n0 + r) * p.ldw + c * 8;
+    }
+    const int nk = p.K / BK;
+
+    auto issue = [&](int kt, int buf) {
+        long long aoff;
+        if (CONV) {
+            const int k0 = kt * BK;
+            const int tap = k0 / p.cg.Cin, c0 = k0 - tap * p.cg.Cin;
+            const int khw = p.cg.kh * p.cg.kw;
+            const int dt = tap / khw, r2 = tap - dt * khw;
+            const int dh = r2 / p.cg.kw, dw = r2 - dh * p.cg.kw;
+            aoff = (((long long)dt * p.cg.Hp + dh) * p.cg.Wp + dw) * p.cg.Cin + c0;
+        } else {
+            aoff = (long long)kt * BK;
+        }
+        char* base = smem + buf * BUF_BYTES + wid * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(asrc[j] + aoff, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(wsrc[j] + (long long)kt * BK, base + TILE_BYTES + j * 1024);
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = wid >> 1, wn = wid & 1;
+    // fragment read addressing: row = tile_row0 + (lane&31); chunk = 2*ks + (lane>>5), swizzled
+    const int frow = lane & 31, fhi = lane >> 5, fswz = (lane >> 1) & 7;
+    const int a_row_off = (wm * 64 + frow) * 128;
+    const int w_row_off = (wn * 64 + frow) * 128;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        const char* sa = smem + buf * BUF_BYTES;
+        const char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ((2 * ks + fhi) ^ fswz) << 4;
+            bf16x8_t af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *(const bf16x8_t*)(sa + a_row_off + i * 32 * 128 + ch);
+                wf[i] = *(const bf16x8_t*)(sw + w_row_off + i * 32 * 128 + ch);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: stage fp32 accumulators in LDS (128x128 fp32 = 64 KiB) ----
+    __builtin_amdgcn_s_barrier();
+    float* st = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                const int col = wn * 64 + j * 32 + frow;
+                st[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int col = (tid & 15) * 8;
+    const int n = n0 + col;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = p.bias ? p.bias[n + e] : 0.f;
+    float gate[8];
+    if (p.flags & PF_GEMM_GATE_RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gate[e] = p.gate ? p.gate[(long long)b * p.gate_stride + n + e] : 1.f;
+    }
+    const bool do_gelu = n >= p.gelu_from;
+    if (n >= p.n_valid) return;
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = pass * 16 + (tid >> 4);
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float v[8];
+        const f32x4_t v0 = *(const f32x4_t*)(st + row * BN + col);
+        const f32x4_t v1 = *(const f32x4_t*)(st + row * BN + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias[e]; v[4 + e] = v1[e] + bias[4 + e]; }
+        if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+        }
+        long long coff;
+        if (CONV && p.om.mode == 1) {
+            const int hw = p.om.H * p.om.W;
+            const int tt = m / hw, rem = m - tt * hw;
+            const int hh = rem / p.om.W, ww = rem - hh * p.om.W;
+            const int g = n / p.om.Cg, cc = n - g * p.om.Cg;
+            const int shw = p.om.sh * p.om.sw;
+            const int pt = g / shw, g2 = g - pt * shw;
+            const int ph = g2 / p.om.sw, pw = g2 - ph * p.om.sw;
+            coff = p.om.base_off +
+                   (((long long)(tt * p.om.st + pt) * p.om.Hop + (hh * p.om.sh + ph)) * p.om.Wop + (ww * p.om.sw + pw)) *
+                       p.om.Cout_pitch + cc;
+        } else {
+            coff = (long long)b * p.sC + (long long)m * p.ldc + n;
+        }
+        if (p.flags & PF_GEMM_GATE_RES) {
+            float rv[8];
+            const long long roff = (CONV && p.om.mode == 1) ? coff : ((long long)b * p.sR + (long long)m * p.ldr + n);
+            unpack8(*(const u32x4_t*)(p.res + roff), rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rv[e] + gate[e] * v[e];
+        }
+        if (p.out_scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        }
+        if (p.flags & PF_GEMM_OUT_F32) {
+            float* c = (float*)p.C + coff;
+            *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
+            *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+        } else {
+            *(u32x4_t*)((bf16_t*)p.C + coff) = pack8(v);
+        }
+    }
+}
+
+}  // namespace
+
+int pf_set_err(const char* m);
+#define set_err pf_set_err
+
+extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
+    if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
+    if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
+    if (d->N % BN != 0) return set_err("pf_gemm_bf16: N must be a multiple of 128");
+    if (d->K % BK != 0 || d->K <= 0) return set_err("pf_gemm_bf16: K must be a positive multiple of 64");
+    if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8)) return set_err("pf_gemm_bf16: leading dims must be multiples of 8");
+    if ((d->flags & PF_GEMM_GATE_RES) && !d->res) return set_err("pf_gemm_bf16: GATE_RES needs res");
+    Args a{};
+    a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C;
+    a.bias = d->bias; a.res = (const bf16_t*)d->res; a.gate = d->gate;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldr = d->ldr;
+    a.sA = d->strideA; a.sC = d->strideC; a.sR = d->strideR; a.gate_stride = d->gate_stride; a.batch = d->batch;
+    a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
+    a.out_scale = 1.f; a.n_valid = d->N;
+    if (a.gelu_from % 8) return set_err("pf_gemm_bf16: gelu_from must be a multiple of 8");
+    const int grid = (d->N / BN) * ((d->M + BM - 1) / BM) * d->batch;
+    hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipLaunchKernelGGL(gemm_kernel<false>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
+    if (!d || !d->X || !d->W || !d->Y) return set_err("pf_conv3d_bf16: null operand");
+    const int ntaps = d->kt * d->kh * d->kw;
+    const int K = ntaps * d->Cin;
+    if (d->Cin % BK != 0) return set_err("pf_conv3d_bf16: Cin must be a multiple of 64 (pad channels)");
+    if (d->N % BN != 0) return set_err("pf_conv3d_bf16: N must be a multiple of 128 (pad filters)");
+    if (d->T <= 0 || d->H <= 0 || d->W_ <= 0) return set_err("pf_conv3d_bf16: empty problem");
+    Args a{};
+    a.A = (const bf16_t*)d->X; a.W = (const bf16_t*)d->W; a.C = d->Y;
+    a.bias = d->bias; a.res = (const bf16_t*)d->res; a.gate = nullptr;
+    a.M = d->T * d->H * d->W_; a.N = d->N; a.K = K; a.lda = 0; a.ldw = K; a.ldc = d->N; a.ldr = d->N;
+    a.sA = 0; a.sC = 0; a.sR = 0; a.gate_stride = 0; a.batch = 1;
+    a.gelu_from = d->N; a.flags = d->flags; a.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
+    a.n_valid = d->n_valid > 0 ? d->n_valid : d->N;
+    a.cg = ConvGeom{d->H, d->W_, d->Hp, d->Wp, d->Cin, d->kt, d->kh, d->kw, d->in_base_off};
+    a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch};
+    if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
+    const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
+    hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipLaunchKernelGGL(gemm_kernel<true>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(hipGetErrorString(e));
+    return 0;
+}

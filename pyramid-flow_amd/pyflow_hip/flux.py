@@ -1,0 +1,289 @@
+"""miniFLUX DiT forward on MI355X: weight packing + kernel sequencing.
+
+Mirrors ``PyramidFluxTransformer.forward`` (pyramid_dit/flux_modules/modeling_pyramid_flux.py:392-542)
+for one pyramid stage per call (the only form inference uses, pipeline.py:760).  The token layout is
+ONE buffer ``hidden[B][Lt + L_img][d]`` (text rows first) for all double and single blocks -- the
+reference's `cat([text, image])` at :480 is the identity here, so there is no re-partition step.
+Fused projections: per double block K|V|Q share one GEMM per stream; per single block K|V|Q|MLP
+(N = 7d) with the GELU fused on the MLP columns; attention writes O over the Q columns so that the
+out-projection reads `[O | mlp]` (= the reference's `cat([attn, mlp])`, flux_block.py:936) in place.
+"""
+import torch
+
+from . import ops
+from .ops import GEMM_GATE_RES, GEMM_OUT_F32
+from .plan import SequencePlan
+
+
+def _bf16(t, device):
+    return t.detach().to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _pad_k(w, mult=64):
+    k = w.shape[1]
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return w
+    out = torch.zeros(w.shape[0], kp, dtype=w.dtype)
+    out[:, :k] = w
+    return out
+
+
+def _pad_n(w, b, mult=128):
+    n = w.shape[0]
+    np_ = (n + mult - 1) // mult * mult
+    if np_ == n:
+        return w, b
+    wo = torch.zeros(np_, w.shape[1], dtype=w.dtype)
+    wo[:n] = w
+    bo = torch.zeros(np_, dtype=b.dtype)
+    bo[:n] = b
+    return wo, bo
+
+
+class FluxWeights:
+    """Packs a reference-keyed state dict (SURVEY 8b key layout) into fused bf16 matrices."""
+
+    def __init__(self, sd, cfg, device):
+        sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self.cfg = cfg
+        H, hd = cfg["num_attention_heads"], cfg["attention_head_dim"]
+        assert hd == 64, "attention kernel is specialised for head_dim 64"
+        d = H * hd
+        assert d % 128 == 0, "model width must be a multiple of 128"
+        self.d, self.H = d, H
+        nd, ns = cfg["num_layers"], cfg["num_single_layers"]
+        dev = device
+
+        def W(name):
+            return sd[name + ".weight"]
+
+        def Bv(name):
+            return sd[name + ".bias"]
+
+        # conditioning MLPs (gemv, bf16 weights / fp32 bias)
+        self.t1 = (_bf16(W("time_text_embed.timestep_embedder.linear_1"), dev), _f32(Bv("time_text_embed.timestep_embedder.linear_1"), dev))
+        self.t2 = (_bf16(W("time_text_embed.timestep_embedder.linear_2"), dev), _f32(Bv("time_text_embed.timestep_embedder.linear_2"), dev))
+        self.p1 = (_bf16(_pad_k(W("time_text_embed.text_embedder.linear_1"), 8), dev), _f32(Bv("time_text_embed.text_embedder.linear_1"), dev))
+        self.p2 = (_bf16(W("time_text_embed.text_embedder.linear_2"), dev), _f32(Bv("time_text_embed.text_embedder.linear_2"), dev))
+        self.pooled_k = self.p1[0].shape[1]
+        # embedders
+        self.ctx_w = _bf16(_pad_k(W("context_embedder")), dev)
+        self.ctx_b = _f32(Bv("context_embedder"), dev)
+        self.ctx_k = self.ctx_w.shape[1]
+        self.x_w = _bf16(_pad_k(W("x_embedder")), dev)
+        self.x_b = _f32(Bv("x_embedder"), dev)
+        self.in_ch = W("x_embedder").shape[1]
+        assert self.x_w.shape[1] == self.in_ch, "in_channels must be a multiple of 64"
+        # all AdaLN linears as one matrix (one gemv per forward)
+        mods, mod_b = [], []
+        self.dbl, self.sgl = [], []
+        off = 0
+        for i in range(nd):
+            p = f"transformer_blocks.{i}."
+            mods += [W(p + "norm1.linear"), W(p + "norm1_context.linear")]
+            mod_b += [Bv(p + "norm1.linear"), Bv(p + "norm1_context.linear")]
+            blk = dict(mod=off)
+            off += 12 * d
+            blk["kvq_img"] = (_bf16(torch.cat([W(p + "attn.to_k"), W(p + "attn.to_v"), W(p + "attn.to_q")]), dev),
+                              _f32(torch.cat([Bv(p + "attn.to_k"), Bv(p + "attn.to_v"), Bv(p + "attn.to_q")]), dev))
+            blk["kvq_txt"] = (_bf16(torch.cat([W(p + "attn.add_k_proj"), W(p + "attn.add_v_proj"), W(p + "attn.add_q_proj")]), dev),
+                              _f32(torch.cat([Bv(p + "attn.add_k_proj"), Bv(p + "attn.add_v_proj"), Bv(p + "attn.add_q_proj")]), dev))
+            blk["o_img"] = (_bf16(W(p + "attn.to_out.0"), dev), _f32(Bv(p + "attn.to_out.0"), dev))
+            blk["o_txt"] = (_bf16(W(p + "attn.to_add_out"), dev), _f32(Bv(p + "attn.to_add_out"), dev))
+            blk["ff1_img"] = (_bf16(W(p + "ff.net.0.proj"), dev), _f32(Bv(p + "ff.net.0.proj"), dev))
+            blk["ff2_img"] = (_bf16(W(p + "ff.net.2"), dev), _f32(Bv(p + "ff.net.2"), dev))
+            blk["ff1_txt"] = (_bf16(W(p + "ff_context.net.0.proj"), dev), _f32(Bv(p + "ff_context.net.0.proj"), dev))
+            blk["ff2_txt"] = (_bf16(W(p + "ff_context.net.2"), dev), _f32(Bv(p + "ff_context.net.2"), dev))
+            for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                blk[nm] = _f32(sd[p + f"attn.{nm}.weight"], dev)
+            self.dbl.append(blk)
+        for j in range(ns):
+            p = f"single_transformer_blocks.{j}."
+            mods.append(W(p + "norm.linear"))
+            mod_b.append(Bv(p + "norm.linear"))
+            blk = dict(mod=off)
+            off += 3 * d
+            blk["kvqm"] = (_bf16(torch.cat([W(p + "attn.to_k"), W(p + "attn.to_v"), W(p + "attn.to_q"), W(p + "proj_mlp")]), dev),
+                           _f32(torch.cat([Bv(p + "attn.to_k"), Bv(p + "attn.to_v"), Bv(p + "attn.to_q"), Bv(p + "proj_mlp")]), dev))
+            blk["out"] = (_bf16(W(p + "proj_out"), dev), _f32(Bv(p + "proj_out"), dev))
+            blk["norm_q"] = _f32(sd[p + "attn.norm_q.weight"], dev)
+            blk["norm_k"] = _f32(sd[p + "attn.norm_k.weight"], dev)
+            self.sgl.append(blk)
+        mods.append(W("norm_out.linear"))
+        mod_b.append(Bv("norm_out.linear"))
+        self.mod_final = off
+        off += 2 * d
+        self.n_mod = off
+        self.mod_w = _bf16(torch.cat(mods), dev)
+        self.mod_b = _f32(torch.cat(mod_b), dev)
+        pw, pb = _pad_n(W("proj_out"), Bv("proj_out"))
+        self.proj_w, self.proj_b = _bf16(pw, dev), _f32(pb, dev)
+        self.out_cols = W("proj_out").shape[0]
+        self.n_params = sum(v.numel() for v in sd.values())
+
+
+class FluxEngine:
+    def __init__(self, state_dict, cfg, device="cuda"):
+        self.dev = torch.device(device)
+        self.w = FluxWeights(state_dict, cfg, self.dev)
+        self.cfg = cfg
+        self._ws = {}
+        self._ctx = None
+
+    # ---- workspace (grow-only) ----
+    def _buf(self, name, numel, dtype):
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = torch.zeros(numel, dtype=dtype, device=self.dev) if name == "vT" \
+                else torch.empty(numel, dtype=dtype, device=self.dev)
+            self._ws[name] = t
+        return t
+
+    def make_plan(self, clip_shapes, enc_mask):
+        return SequencePlan(clip_shapes, enc_mask, self.cfg["axes_dims_rope"], self.dev)
+
+    def encode_context(self, enc):
+        """context_embedder (flux:401): enc [B, Lt, C] -> cached bf16 [B, Lt, d]."""
+        w = self.w
+        B, Lt, Cc = enc.shape
+        x = torch.zeros(B * Lt, w.ctx_k, dtype=torch.bfloat16, device=self.dev)
+        x[:, :Cc] = enc.reshape(B * Lt, Cc).to(self.dev, torch.bfloat16)
+        out = torch.empty(B, Lt, w.d, dtype=torch.bfloat16, device=self.dev)
+        ops.gemm(x, w.ctx_w, out, B * Lt, w.d, w.ctx_k, w.ctx_k, w.ctx_k, w.d, bias=w.ctx_b)
+        self._ctx = out
+        self._ctx_keep = x
+        return out
+
+    def conditioning(self, timesteps, pooled):
+        """time_text_embed (modeling_embedding.py:185-200) + every block's AdaLN linear -> mod [B, n_mod] fp32."""
+        w = self.w
+        B = len(timesteps)
+        d = w.d
+        tproj = self._buf("tproj", B * 256, torch.float32).view(B, 256)
+        ops.timestep_embed(tproj, timesteps, 256)
+        h1 = self._buf("h1", B * d, torch.float32)
+        temb = self._buf("temb", B * d, torch.float32)
+        ops.gemv(w.t1[0], w.t1[1], tproj, h1, d, 256, B)
+        ops.gemv(w.t2[0], w.t2[1], h1, temb, d, d, B, silu_in=True)
+        pk = w.pooled_k
+        pp = torch.zeros(B, pk, dtype=torch.float32, device=self.dev)
+        pp[:, :pooled.shape[1]] = pooled.to(self.dev, torch.float32)
+        ops.gemv(w.p1[0], w.p1[1], pp, h1, d, pk, B)
+        ops.gemv(w.p2[0], w.p2[1], h1, temb, d, d, B, silu_in=True, accumulate=True)
+        mod = self._buf("mod", B * w.n_mod, torch.float32)
+        ops.gemv(w.mod_w, w.mod_b, temb, mod, w.n_mod, d, B, silu_in=True)
+        return mod, temb
+
+    def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):
+        """clips: list of device tensors [B,C,t,h,w] (or [1,C,t,h,w] with shared_clips=True: the CFG
+        duplicate of pipeline.py:747).  Returns v tokens fp32 [B, n_cur, 128] (first 4C columns valid)."""
+        w = self.w
+        d, H = w.d, w.H
+        B, Lt, L, L_img, Lp = plan.B, plan.Lt, plan.L, plan.L_img, plan.Lp
+        ctx = ctx if ctx is not None else self._ctx
+        mod, _ = self.conditioning(timesteps, pooled)
+        nm = w.n_mod
+        hidden = self._buf("hidden", B * L * d, torch.bfloat16)
+        xn = self._buf("xn", B * L * d, torch.bfloat16)
+        big = self._buf("big", B * L * 7 * d, torch.bfloat16)
+        vT = self._buf("vT", B * H * 64 * Lp, torch.bfloat16)
+        tok = self._buf("tok", B * L_img * w.in_ch, torch.bfloat16)
+        Ld, L3, L4, L7 = L * d, L * 3 * d, L * 4 * d, L * 7 * d
+        mlp_base = B * L3          # mlp region of `big` for the double blocks
+        scale = 64 ** -0.5
+
+        # ---- embed: text rows <- cached context, image rows <- x_embedder(patchify) ----
+        ops.copy_rows(ctx, hidden, Lt, d, d, d, Lt * d, Ld, B)
+        row = 0
+        for cl, n in zip(clips, plan.clip_tokens):
+            Cc, t, h, wd = cl.shape[1:]
+            if shared_clips:
+                ops.patchify(cl[0], tok, row * w.in_ch, Cc, t, h, wd, w.in_ch, L_img * w.in_ch, B)
+            else:
+                for b in range(B):
+                    ops.patchify(cl[b], tok, (b * L_img + row) * w.in_ch, Cc, t, h, wd, w.in_ch, 0, 1)
+            row += n
+        ops.gemm(tok, w.x_w, hidden, L_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
+                 strideA=L_img * w.in_ch, strideC=Ld, c_off=Lt * d)
+        if debug is not None:
+            debug["hidden0"] = hidden[:B * L * d].view(B, L, d).clone()
+
+        def ln(rows, x_off, sh, sc):
+            ops.ln_modulate(hidden, xn, (mod, sh), (mod, sc), d, B, rows, Ld, Ld, d, d, nm, x_off=x_off, y_off=x_off)
+
+        for blk in w.dbl:
+            mb = blk["mod"]
+            ln(L_img, Lt * d, mb + 0, mb + d)
+            ln(Lt, 0, mb + 6 * d, mb + 7 * d)
+            ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                     strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
+            ops.gemm(xn, blk["kvq_txt"][0], big, Lt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
+                     strideA=Ld, strideC=L3)
+            ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
+                             blk["norm_added_k"], plan.rope, B, L, Lt, H)
+            ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
+            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale)
+            ops.gemm(big, blk["o_img"][0], hidden, L_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
+                     gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
+                     flags=GEMM_GATE_RES, a_off=Lt * 3 * d + 2 * d, c_off=Lt * d, r_off=Lt * d)
+            ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
+                     gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
+                     flags=GEMM_GATE_RES, a_off=2 * d)
+            ln(L_img, Lt * d, mb + 3 * d, mb + 4 * d)
+            ln(Lt, 0, mb + 9 * d, mb + 10 * d)
+            ops.gemm(xn, blk["ff1_img"][0], big, L_img, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
+                     strideA=Ld, strideC=L4, gelu_from=0, a_off=Lt * d, c_off=mlp_base + Lt * 4 * d)
+            ops.gemm(big, blk["ff2_img"][0], hidden, L_img, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
+                     res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
+                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + Lt * 4 * d, c_off=Lt * d, r_off=Lt * d)
+            ops.gemm(xn, blk["ff1_txt"][0], big, Lt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
+                     strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
+            ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
+                     res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
+                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
+            if debug is not None and "hidden_d0" not in debug:
+                debug["hidden_d0"] = hidden[:B * L * d].view(B, L, d).clone()
+
+        for blk in w.sgl:
+            mb = blk["mod"]
+            ln(L, 0, mb, mb + d)
+            ops.gemm(xn, blk["kvqm"][0], big, L, 7 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
+                     strideC=L7, gelu_from=3 * d)
+            ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H)
+            ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
+            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale)
+            ops.gemm(big, blk["out"][0], hidden, L, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
+                     gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
+                     flags=GEMM_GATE_RES, a_off=2 * d)
+        if debug is not None:
+            debug["hidden_final"] = hidden[:B * L * d].view(B, L, d).clone()
+
+        # ---- norm_out + proj_out on the current frame's tokens only (split_output keeps [-n_cur:], flux:380) ----
+        n_cur = plan.n_cur
+        fo = (L - n_cur) * d
+        mf = w.mod_final
+        ops.ln_modulate(hidden, xn, (mod, mf + d), (mod, mf), d, B, n_cur, Ld, Ld, d, d, nm, x_off=fo, y_off=fo)
+        npad = w.proj_w.shape[0]
+        vtok = self._buf("vtok", B * n_cur * npad, torch.float32)
+        ops.gemm(xn, w.proj_w, vtok, n_cur, npad, d, d, d, npad, bias=w.proj_b, batch=B, strideA=Ld,
+                 strideC=n_cur * npad, flags=GEMM_OUT_F32, a_off=fo)
+        return vtok[:B * n_cur * npad].view(B, n_cur, npad)
+
+    def forward(self, clips, enc, enc_mask, pooled, timesteps):
+        """Reference-shaped call: returns [B, C, t, h, w] fp32 of the LAST clip (flux:392-542)."""
+        clips = [c.to(self.dev, torch.float32).contiguous() for c in clips]
+        shapes = [tuple(c.shape[2:]) for c in clips]
+        plan = self.make_plan(shapes, enc_mask)
+        ctx = self.encode_context(enc)
+        vt = self.forward_tokens(plan, clips, [float(t) for t in timesteps], pooled, ctx)
+        B = plan.B
+        t, h, w_ = plan.cur
+        Cc = self.w.out_cols // 4
+        x = vt[:, :, :self.w.out_cols].reshape(B, t, h // 2, w_ // 2, 2, 2, Cc)
+        x = x.permute(0, 1, 2, 4, 3, 5, 6).reshape(B, t, h, w_, Cc).permute(0, 4, 1, 2, 3)
+        return x.contiguous()

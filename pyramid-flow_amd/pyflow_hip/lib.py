@@ -1,0 +1,90 @@
+"""ctypes binding of libpyflow_hip.so (the C ABI in include/pyflow_hip.h).
+
+The product path has NO fallback: if the shared library is missing the import of any op raises.
+Tensors are torch tensors used purely as device-memory handles (``data_ptr()``); every call is
+enqueued on torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpyflow_hip.so")
+
+_lib = None
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+                ("res", C.c_void_p), ("gate", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldw", C.c_int),
+                ("ldc", C.c_int), ("ldr", C.c_int),
+                ("strideA", C.c_longlong), ("strideC", C.c_longlong), ("strideR", C.c_longlong),
+                ("gate_stride", C.c_int), ("batch", C.c_int), ("gelu_from", C.c_int), ("flags", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("Y", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("T", C.c_int), ("H", C.c_int), ("W_", C.c_int),
+                ("Hp", C.c_int), ("Wp", C.c_int), ("Cin", C.c_int), ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("in_base_off", C.c_longlong),
+                ("N", C.c_int), ("n_valid", C.c_int),
+                ("st", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("Cg", C.c_int), ("Hop", C.c_int),
+                ("Wop", C.c_int), ("Cout_pitch", C.c_int),
+                ("out_base_off", C.c_longlong),
+                ("flags", C.c_int), ("out_scale", C.c_float)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+                ("ldq", C.c_int), ("ldk", C.c_int), ("ldo", C.c_int),
+                ("strideQ", C.c_longlong), ("strideK", C.c_longlong), ("strideO", C.c_longlong),
+                ("strideVt_b", C.c_longlong), ("strideVt_h", C.c_longlong),
+                ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("Lp", C.c_int), ("Lt", C.c_int),
+                ("a_lo", C.c_void_p), ("a_hi", C.c_void_p), ("b_hi", C.c_void_p), ("tile_kv_end", C.c_void_p),
+                ("scale", C.c_float)]
+
+
+GEMM_GATE_RES = 1
+GEMM_OUT_F32 = 2
+
+# every symbol include/pyflow_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "pf_last_error", "pf_version", "pf_gemm_bf16", "pf_conv3d_bf16", "pf_attention_bf16", "pf_v_transpose",
+    "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
+    "pf_copy_rows", "pf_renoise_upsample", "pf_avgpool2",
+]
+
+
+class PyflowLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library; raise loudly if it is absent (no CPU / torch fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PyflowLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The MI355X path has no fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.pf_last_error.restype = C.c_char_p
+    lib.pf_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("pyflow_hip: " + load().pf_last_error().decode())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

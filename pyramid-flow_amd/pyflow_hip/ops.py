@@ -1,0 +1,119 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of pyflow_hip.h).
+
+Tensors are device-memory handles only; nothing here computes in torch.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import GemmDesc, AttnDesc, ConvDesc, check, ptr, stream, GEMM_GATE_RES, GEMM_OUT_F32  # noqa: F401
+
+
+def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
+         strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
+         a_off=0, c_off=0, r_off=0, gate_off=0):
+    """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res."""
+    lib = L.load()
+    esz_c = 4 if (flags & GEMM_OUT_F32) else 2
+    d = GemmDesc()
+    d.A = A.data_ptr() + 2 * a_off
+    d.W = W.data_ptr()
+    d.C = Cout.data_ptr() + esz_c * c_off
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = (res.data_ptr() + 2 * r_off) if res is not None else None
+    d.gate = (gate.data_ptr() + 4 * gate_off) if gate is not None else None
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr = M, N, K, lda, ldw, ldc, ldr
+    d.strideA, d.strideC, d.strideR = strideA, strideC, strideR
+    d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
+    check(lib.pf_gemm_bf16(C.byref(d), stream()))
+
+
+def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale):
+    lib = L.load()
+    d = AttnDesc()
+    d.Q = Q.data_ptr() + 2 * q_off
+    d.K = K.data_ptr() + 2 * k_off
+    d.Vt = Vt.data_ptr()
+    d.O = O.data_ptr() + 2 * o_off
+    d.ldq = d.ldk = d.ldo = ld
+    d.strideQ = d.strideK = d.strideO = bstride
+    d.strideVt_b = H * 64 * Lp
+    d.strideVt_h = 64 * Lp
+    d.B, d.H, d.L, d.Lp, d.Lt = B, H, Lseq, Lp, Lt
+    d.a_lo, d.a_hi, d.b_hi = plan.a_lo.data_ptr(), plan.a_hi.data_ptr(), plan.b_hi.data_ptr()
+    d.tile_kv_end = plan.tile_kv_end.data_ptr()
+    d.scale = scale
+    check(lib.pf_attention_bf16(C.byref(d), stream()))
+
+
+def v_transpose(V, Vt, v_off, ldv, strideV, B, H, Lseq, Lp):
+    lib = L.load()
+    check(lib.pf_v_transpose(C.c_void_p(V.data_ptr() + 2 * v_off), ptr(Vt), C.c_int(ldv), C.c_longlong(strideV),
+                             C.c_longlong(H * 64 * Lp), C.c_longlong(64 * Lp), C.c_int(B), C.c_int(H),
+                             C.c_int(Lseq), C.c_int(Lp), stream()))
+
+
+def ln_modulate(x, y, shift, scale, D, B, rows, x_bstride, y_bstride, ldx, ldy, mod_bstride,
+                x_off=0, y_off=0, eps=1e-6):
+    """shift/scale: (tensor, element offset) pairs into the fp32 modulation buffer."""
+    lib = L.load()
+    sh = C.c_void_p(shift[0].data_ptr() + 4 * shift[1])
+    sc = C.c_void_p(scale[0].data_ptr() + 4 * scale[1])
+    check(lib.pf_ln_modulate(C.c_void_p(x.data_ptr() + 2 * x_off), C.c_void_p(y.data_ptr() + 2 * y_off), sh, sc,
+                             C.c_int(D), C.c_int(B), C.c_int(rows), C.c_longlong(x_bstride),
+                             C.c_longlong(y_bstride), C.c_int(ldx), C.c_int(ldy), C.c_int(mod_bstride),
+                             C.c_float(eps), stream()))
+
+
+def qk_norm_rope(qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt, wk_txt, rope, B, Lseq, Lt, H, eps=1e-6):
+    lib = L.load()
+    check(lib.pf_qk_norm_rope(ptr(qkv), C.c_int(ld), C.c_longlong(bstride), C.c_int(q_off), C.c_int(k_off),
+                              ptr(wq_img), ptr(wk_img), ptr(wq_txt), ptr(wk_txt), ptr(rope), C.c_int(B),
+                              C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), stream()))
+
+
+def gemv(W, bias, x, y, N, K, B, ldw=None, ldx=None, ldy=None, silu_in=False, accumulate=False, y_off=0):
+    lib = L.load()
+    check(lib.pf_gemv_f32(ptr(W), C.c_int(ldw or K), ptr(bias), ptr(x), C.c_int(ldx or K),
+                          C.c_void_p(y.data_ptr() + 4 * y_off), C.c_int(ldy or N), C.c_int(N), C.c_int(K),
+                          C.c_int(B), C.c_int(int(silu_in)), C.c_int(int(accumulate)), stream()))
+
+
+def timestep_embed(out, ts, dim=256):
+    lib = L.load()
+    arr = (C.c_float * len(ts))(*[float(t) for t in ts])
+    check(lib.pf_timestep_embed(ptr(out), C.c_int(out.stride(0)), C.c_int(len(ts)), arr, C.c_int(dim), stream()))
+
+
+def patchify(x, tok, tok_off, Cc, T, H, W, ld, bstride, ncopies):
+    lib = L.load()
+    check(lib.pf_patchify(ptr(x), C.c_int(int(x.dtype == torch.float32)), C.c_void_p(tok.data_ptr() + 2 * tok_off),
+                          C.c_int(Cc), C.c_int(T), C.c_int(H), C.c_int(W), C.c_int(ld), C.c_longlong(bstride),
+                          C.c_int(ncopies), stream()))
+
+
+def cfg_euler_step(v, vb_stride, ld, x, Cc, H, W, guidance, use_cfg, dsigma, round_bf16):
+    lib = L.load()
+    check(lib.pf_cfg_euler_step(ptr(v), C.c_longlong(vb_stride), C.c_int(ld), ptr(x), C.c_int(Cc), C.c_int(H),
+                                C.c_int(W), C.c_float(guidance), C.c_int(int(use_cfg)), C.c_float(dsigma),
+                                C.c_int(int(round_bf16)), stream()))
+
+
+def copy_rows(src, dst, rows, D, ld_src, ld_dst, src_bstride, dst_bstride, B, dst_off=0, src_off=0):
+    lib = L.load()
+    check(lib.pf_copy_rows(C.c_void_p(src.data_ptr() + 2 * src_off), C.c_void_p(dst.data_ptr() + 2 * dst_off),
+                           C.c_int(rows), C.c_int(D), C.c_int(ld_src), C.c_int(ld_dst), C.c_longlong(src_bstride),
+                           C.c_longlong(dst_bstride), C.c_int(B), stream()))
+
+
+def renoise_upsample(xin, noise, xout, Cc, H, W, alpha, beta, round_bf16):
+    lib = L.load()
+    check(lib.pf_renoise_upsample(ptr(xin), ptr(noise), ptr(xout), C.c_int(Cc), C.c_int(H), C.c_int(W),
+                                  C.c_float(alpha), C.c_float(beta), C.c_int(int(round_bf16)), stream()))
+
+
+def avgpool2(xin, xout, planes, H, W, mul=1.0, round_bf16=False):
+    lib = L.load()
+    check(lib.pf_avgpool2(ptr(xin), ptr(xout), C.c_longlong(planes), C.c_int(H), C.c_int(W), C.c_float(mul),
+                          C.c_int(int(round_bf16)), stream()))

@@ -1,0 +1,136 @@
+"""Synthetic (random-init) weights with the reference's state-dict key layout.
+
+No checkpoints exist in this environment: the benchmark and the tests use random weights of the
+released architectures.  Key names/shapes are checked against the instantiated reference modules in
+tests/test_oracle_vs_reference.py.
+"""
+from collections import OrderedDict
+
+import torch
+
+MINIFLUX = dict(num_layers=8, num_single_layers=16, num_attention_heads=30, attention_head_dim=64,
+                in_channels=64, joint_attention_dim=4096, pooled_projection_dim=768,
+                axes_dims_rope=[16, 24, 24])
+TINY_FLUX = dict(num_layers=2, num_single_layers=2, num_attention_heads=4, attention_head_dim=64,
+                 in_channels=64, joint_attention_dim=32, pooled_projection_dim=16,
+                 axes_dims_rope=[16, 24, 24])
+VAE_DEFAULT = dict(latent_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=(3, 3, 3, 3),
+                   spatial_up_sample=(True, True, True, False), temporal_up_sample=(True, True, True, False),
+                   out_channels=3, norm_num_groups=32)
+TINY_VAE = dict(latent_channels=16, block_out_channels=(32, 32, 64, 64), layers_per_block=(2, 2, 2, 2),
+                spatial_up_sample=(True, True, True, False), temporal_up_sample=(True, True, True, False),
+                out_channels=3, norm_num_groups=32)
+
+
+def flux_param_shapes(cfg):
+    d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    hd = cfg["attention_head_dim"]
+    s = OrderedDict()
+
+    def lin(name, o, i):
+        s[name + ".weight"] = (o, i)
+        s[name + ".bias"] = (o,)
+
+    lin("time_text_embed.timestep_embedder.linear_1", d, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", d, d)
+    lin("time_text_embed.text_embedder.linear_1", d, cfg["pooled_projection_dim"])
+    lin("time_text_embed.text_embedder.linear_2", d, d)
+    lin("context_embedder", d, cfg["joint_attention_dim"])
+    lin("x_embedder", d, cfg["in_channels"])
+    for i in range(cfg["num_layers"]):
+        p = f"transformer_blocks.{i}."
+        lin(p + "norm1.linear", 6 * d, d)
+        lin(p + "norm1_context.linear", 6 * d, d)
+        s[p + "attn.norm_q.weight"] = (hd,)
+        s[p + "attn.norm_k.weight"] = (hd,)
+        for n in ("to_q", "to_k", "to_v", "add_k_proj", "add_v_proj", "add_q_proj"):
+            lin(p + "attn." + n, d, d)
+        lin(p + "attn.to_out.0", d, d)
+        lin(p + "attn.to_add_out", d, d)
+        s[p + "attn.norm_added_q.weight"] = (hd,)
+        s[p + "attn.norm_added_k.weight"] = (hd,)
+        lin(p + "ff.net.0.proj", 4 * d, d)
+        lin(p + "ff.net.2", d, 4 * d)
+        lin(p + "ff_context.net.0.proj", 4 * d, d)
+        lin(p + "ff_context.net.2", d, 4 * d)
+    for i in range(cfg["num_single_layers"]):
+        p = f"single_transformer_blocks.{i}."
+        lin(p + "norm.linear", 3 * d, d)
+        lin(p + "proj_mlp", 4 * d, d)
+        lin(p + "proj_out", d, 5 * d)
+        s[p + "attn.norm_q.weight"] = (hd,)
+        s[p + "attn.norm_k.weight"] = (hd,)
+        for n in ("to_q", "to_k", "to_v"):
+            lin(p + "attn." + n, d, d)
+    lin("norm_out.linear", 2 * d, d)
+    lin("proj_out", cfg["in_channels"], d)
+    return s
+
+
+def vae_decoder_param_shapes(cfg):
+    """decoder + post_quant_conv of CausalVideoVAE (video_vae/modeling_causal_vae.py:137-153)."""
+    s = OrderedDict()
+    boc = cfg["block_out_channels"]
+    lat = cfg["latent_channels"]
+
+    def conv(name, co, ci, k):
+        s[name + ".conv.weight"] = (co, ci, k, k, k)
+        s[name + ".conv.bias"] = (co,)
+
+    def norm(name, c):
+        s[name + ".weight"] = (c,)
+        s[name + ".bias"] = (c,)
+
+    def resnet(p, ci, co):
+        norm(p + "norm1", ci)
+        conv(p + "conv1", co, ci, 3)
+        norm(p + "norm2", co)
+        conv(p + "conv2", co, co, 3)
+        if ci != co:
+            conv(p + "conv_shortcut", co, ci, 1)
+
+    top = boc[-1]
+    conv("decoder.conv_in", top, lat, 3)
+    resnet("decoder.mid_block.resnets.0.", top, top)
+    a = "decoder.mid_block.attentions.0."
+    norm(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[a + n + ".weight"] = (top, top)
+        s[a + n + ".bias"] = (top,)
+    resnet("decoder.mid_block.resnets.1.", top, top)
+    rev = list(reversed(boc))
+    prev = rev[0]
+    for i, co in enumerate(rev):
+        p = f"decoder.up_blocks.{i}."
+        for j in range(cfg["layers_per_block"][i]):
+            resnet(p + f"resnets.{j}.", prev if j == 0 else co, co)
+        if cfg["spatial_up_sample"][i]:
+            conv(p + "upsamplers.0.conv", co * 4, co, 3)
+        if cfg["temporal_up_sample"][i]:
+            conv(p + "temporal_upsamplers.0.conv", co * 2, co, 3)
+        prev = co
+    norm("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out", cfg["out_channels"], boc[0], 3)
+    conv("post_quant_conv", lat, lat, 1)
+    return s
+
+
+def random_state_dict(shapes, seed=1234, std=0.02, lively=False, dtype=torch.float32):
+    """N(0, std^2) matrices, norm gains 1, biases 0.  lively=True perturbs gains and
+    biases too (tests: exercises every term)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for k, shp in shapes.items():
+        is_gain = len(shp) == 1 and k.endswith(".weight")
+        if is_gain:
+            t = torch.ones(shp)
+            if lively:
+                t = t + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            t = torch.zeros(shp)
+            if lively:
+                t = std * torch.randn(shp, generator=g)
+        else:
+            t = std * torch.randn(shp, generator=g)
+        sd[k] = t.to(dtype)
+    return sd

@@ -1,0 +1,33 @@
+"""The C-ABI library loads and exports every symbol include/pyflow_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pyflow_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pyflow_hip import lib
+    names = _declared()
+    assert len(names) >= 15
+    assert os.path.isfile(lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    so = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+    assert sorted(lib.EXPORTS) == names
+    assert lib.load().pf_version() >= 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pyflow_hip import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libpyflow_hip.so")
+    import pytest
+    with pytest.raises(lib.PyflowLibraryMissing):
+        lib.load()

@@ -1,0 +1,66 @@
+"""GPU parity: whole miniFLUX DiT forward (HIP path, bf16) vs the CPU fp32 oracle, same bf16-rounded weights.
+Tolerance: one DiT forward rel-L2 <= 2e-2."""
+import pytest
+import torch
+
+from util import rel_l2, round_sd
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(clip_shapes, B=2, Lt=16, C=32, Cp=16, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    clips = [torch.randn(B, 16, *s, generator=g) for s in clip_shapes]
+    enc = torch.randn(B, Lt, C, generator=g)
+    mask = torch.zeros(B, Lt, dtype=torch.long)
+    mask[0, :5] = 1
+    mask[1, :12] = 1
+    pooled = torch.randn(B, Cp, generator=g)
+    return clips, enc, mask, pooled
+
+
+@pytest.mark.parametrize("clip_shapes", [
+    [(1, 16, 32)],
+    [(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)],
+])
+def test_tiny_forward_vs_oracle(clip_shapes):
+    from pyflow_hip.flux import FluxEngine
+    from pyflow_hip import synth
+    from oracle.flux_oracle import flux_forward
+    cfg = synth.TINY_FLUX
+    sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05, lively=True))
+    clips, enc, mask, pooled = _inputs(clip_shapes)
+    clips = [c.to(torch.bfloat16).float() for c in clips]
+    enc = enc.to(torch.bfloat16).float()
+    t = torch.tensor([704.0, 704.0])
+    ref, inter = flux_forward(sd, cfg, clips, enc, mask, pooled, t, return_intermediates=True)
+    eng = FluxEngine(sd, cfg, "cuda")
+    dbg = {}
+    clips_d = [c.cuda() for c in clips]
+    plan = eng.make_plan(clip_shapes, mask)
+    ctx = eng.encode_context(enc)
+    eng.forward_tokens(plan, clips_d, [704.0, 704.0], pooled, ctx, debug=dbg)
+    Lt = mask.shape[1]
+    h0 = dbg["hidden0"].float().cpu()
+    assert rel_l2(h0[:, :Lt], inter["c0"]) < 1e-2
+    assert rel_l2(h0[:, Lt:], inter["x0"]) < 1e-2
+    hd0 = dbg["hidden_d0"].float().cpu()
+    assert rel_l2(hd0[:, Lt:], inter["x_after_double0"]) < 1.5e-2
+    assert rel_l2(hd0[:, :Lt], inter["c_after_double0"]) < 1.5e-2
+    assert rel_l2(dbg["hidden_final"].float().cpu()[:, Lt:], inter["x_final"]) < 2e-2
+    out = eng.forward(clips_d, enc, mask, pooled, t).cpu()
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_golden_fixture_forward():
+    """Committed fixture produced by the UNMODIFIED reference (oracle/gen_golden.py)."""
+    import os
+    from pyflow_hip.flux import FluxEngine
+    path = os.path.join(os.path.dirname(__file__), "golden", "flux_tiny_forward.pt")
+    from pyflow_hip import synth
+    g = torch.load(path)
+    sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(g["cfg"]), seed=g["weight_seed"], std=0.05, lively=True))
+    eng = FluxEngine(sd, g["cfg"], "cuda")
+    out = eng.forward([c.cuda() for c in g["clips"]], g["enc"], g["mask"], g["pooled"], g["timestep"]).cpu()
+    assert rel_l2(out, g["out"]) < 2e-2

@@ -1,0 +1,66 @@
+"""Kernel microbenchmarks at the C3 (768p, 241-frame) worst-case shapes. Usage: python tools/microbench.py [gemm|attn|all]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+from pyflow_hip import ops  # noqa: E402
+from pyflow_hip.plan import SequencePlan  # noqa: E402
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench_gemm():
+    d = 1920
+    M = 2 * 15488
+    for (N, K, gelu) in [(d, d, -1), (3 * d, d, -1), (4 * d, d, 0), (d, 4 * d, -1), (7 * d, d, 3 * d), (d, 5 * d, -1)]:
+        A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
+        C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        bias = torch.zeros(N, device="cuda")
+        ms = timeit(lambda: ops.gemm(A, W, C, M, N, K, K, K, N, bias=bias, gelu_from=gelu))
+        print(f"gemm M={M} N={N} K={K} gelu_from={gelu}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+
+def bench_attn():
+    B, H, Lt, d = 2, 30, 128, 1920
+    for name, clips in [("unit30_s2", [(28, 24, 40), (1, 48, 80), (1, 96, 160), (1, 96, 160)]),
+                        ("unit30_s0", [(29, 24, 40), (1, 24, 40), (1, 24, 40)]),
+                        ("unit0_s2", [(1, 96, 160)])]:
+        mask = torch.zeros(B, Lt, dtype=torch.long)
+        mask[0, :40] = 1
+        mask[1, :96] = 1
+        plan = SequencePlan(clips, mask, [16, 24, 24], "cuda")
+        L, Lp = plan.L, plan.Lp
+        qkv = torch.randn(B, L, 3 * d, device="cuda").to(torch.bfloat16)
+        vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device="cuda")
+        ops.v_transpose(qkv, vT, d, 3 * d, L * 3 * d, B, H, L, Lp)
+        out = torch.empty_like(qkv)
+        ms = timeit(lambda: ops.attention(qkv, qkv, vT, out, 2 * d, 0, 2 * d, 3 * d, L * 3 * d, B, H, L, Lp, Lt, plan, 0.125))
+        useful = 4 * plan.useful_pairs() * 64 * H
+        dense = 4 * B * L * L * 64 * H
+        print(f"attn {name} L={L}: {ms:.3f} ms  useful {useful / ms / 1e9:.1f} TFLOP/s (dense-equivalent {dense / ms / 1e9:.1f})", flush=True)
+        ms = timeit(lambda: ops.v_transpose(qkv, vT, d, 3 * d, L * 3 * d, B, H, L, Lp))
+        print(f"v_transpose L={L}: {ms:.3f} ms  {2 * B * L * d * 2 / ms / 1e6:.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("attn", "all"):
+        bench_attn()
