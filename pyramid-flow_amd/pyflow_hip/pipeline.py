@@ -1,0 +1,294 @@
+"""PyramidDiTForVideoGeneration -- drop-in for pyramid_dit/pyramid_dit_for_video_gen_pipeline.py:114-1279
+(inference half: generate / generate_one_unit / decode_latent), driving the HIP engines.
+
+Host loop = the reference's (autoregressive units x pyramid stages x Euler steps, pipeline.py:1126-1203,
+706-788) with these MI355X-side changes, none of which alters the arithmetic:
+  * the per-step DiT call, CFG combine and Euler update never leave the device: the latent state is an fp32
+    device tensor updated in place by pf_cfg_euler_step; timesteps/sigmas are host scalars passed by value;
+  * RoPE tables and the block-causal mask plan are built once per (unit, stage), not per forward;
+  * text embedding of the context (`context_embedder`) is computed once per video;
+  * block-correlated renoise noise is drawn vectorised (one randn(N,4) @ L^T) instead of N Python-loop draws
+    -- same distribution, different stream; `block_noise_fn` lets callers inject the reference's stream;
+  * no gc.collect()/empty_cache() per unit, no per-step broadcast (ranks are bit-deterministic).
+"""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .flux import FluxEngine
+from .scheduler import PyramidFlowMatchEulerDiscreteScheduler
+
+DEFAULT_NEGATIVE = ("cartoon style, worst quality, low quality, blurry, absolute black, absolute white, low res, "
+                    "extra limbs, extra digits, misplaced objects, mutated anatomy, monochrome, horror")
+
+
+def block_noise_cholesky(gamma):
+    cov = torch.eye(4, dtype=torch.float64) * (1 + gamma) - torch.ones(4, 4, dtype=torch.float64) * gamma
+    # rank-deficient by construction (1 + gamma - 4 gamma = 0 at gamma = 1/3): regularise like torch's fp32 path
+    return torch.linalg.cholesky(cov.float()).float()
+
+
+class PyramidDiTForVideoGeneration:
+    def __init__(self, model_path=None, model_dtype="bf16", model_name="pyramid_flux", use_gradient_checkpointing=False,
+                 return_log=True, model_variant="diffusion_transformer_768p", timestep_shift=1.0,
+                 stage_range=[0, 1 / 3, 2 / 3, 1], sample_ratios=[1, 1, 1], scheduler_gamma=1 / 3,
+                 use_mixed_training=False, use_flash_attn=False, load_text_encoder=True, load_vae=True,
+                 max_temporal_length=31, frame_per_unit=1, use_temporal_causal=True, corrupt_ratio=1 / 3,
+                 interp_condition_pos=True, stages=[1, 2, 4], video_sync_group=8, gradient_checkpointing_ratio=0.6,
+                 dit_state_dict=None, dit_config=None, vae_state_dict=None, vae_config=None, text_encoder=None,
+                 device="cuda", **kwargs):
+        if model_name != "pyramid_flux":
+            raise NotImplementedError("round 1 implements the miniFLUX (pyramid_flux) variant; pyramid_mmdit is the next "
+                                      "row of the scope table")
+        assert use_temporal_causal and interp_condition_pos and not use_flash_attn
+        assert frame_per_unit == 1, "fixed unit implementation (pipeline.py:181-186)"
+        self.stages = list(stages)
+        self.sample_ratios = sample_ratios
+        self.model_name = model_name
+        self.model_dtype = model_dtype
+        self._device = torch.device(device)
+        if dit_state_dict is None:
+            dit_state_dict, dit_config = _load_diffusers_dir(os.path.join(model_path, model_variant))
+        self.dit = FluxEngine(dit_state_dict, dit_config, device)
+        self.dit.config = type("Cfg", (), dict(dit_config))()
+        self.text_encoder = text_encoder
+        self.load_text_encoder = load_text_encoder
+        self.vae = None
+        self.load_vae = load_vae
+        if load_vae:
+            from .vae import CausalVideoVAE
+            if vae_state_dict is None and model_path is not None:
+                vae_state_dict, vae_config = _load_diffusers_dir(os.path.join(model_path, "causal_video_vae"))
+            if vae_state_dict is not None:
+                self.vae = CausalVideoVAE(vae_state_dict, vae_config, device)
+        self.vae_shift_factor, self.vae_scale_factor = -0.04, 1 / 1.8726            # :165-167
+        self.vae_video_shift_factor, self.vae_video_scale_factor = -0.2343, 1 / 3.0986
+        self.downsample = 8
+        self.frame_per_unit = frame_per_unit
+        self.max_temporal_length = max_temporal_length
+        self.scheduler = PyramidFlowMatchEulerDiscreteScheduler(shift=timestep_shift, stages=len(self.stages),
+                                                                stage_range=stage_range, gamma=scheduler_gamma)
+        self.sequential_offload_enabled = False
+        self.block_noise_fn = None          # (bs, ch, t, h, w) -> CPU fp32 tensor; None = vectorised global-RNG draw
+        self._plans = {}
+        self.timers = {}
+
+    # ---- reference properties (:1261-1279)
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return torch.bfloat16 if self.model_dtype == "bf16" else torch.float32
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def video_guidance_scale(self):
+        return self._video_guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 0
+
+    def enable_sequential_cpu_offload(self):
+        # 288 GB of HBM: offloading is a no-op by design (pipeline.py:201-211 exists to fit 8-12 GB cards)
+        self.sequential_offload_enabled = False
+
+    # ---- noise (:676-703)
+    def prepare_latents(self, batch_size, num_channels_latents, temp, height, width, dtype, device, generator):
+        shape = (batch_size, num_channels_latents, int(temp), int(height) // self.downsample, int(width) // self.downsample)
+        gdev = generator.device if generator is not None else "cpu"
+        return torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
+
+    def sample_block_noise(self, bs, ch, temp, height, width):
+        if self.block_noise_fn is not None:
+            return self.block_noise_fn(bs, ch, temp, height, width)
+        L = block_noise_cholesky(self.scheduler.config.gamma)
+        n = bs * ch * temp * (height // 2) * (width // 2)
+        z = torch.randn(n, 4) @ L.T
+        z = z.reshape(bs, ch, temp, height // 2, width // 2, 2, 2).permute(0, 1, 2, 3, 5, 4, 6)
+        return z.reshape(bs, ch, temp, height, width)
+
+    # ---- plan cache
+    def _plan(self, shapes, mask):
+        key = (tuple(shapes), mask.cpu().numpy().tobytes())
+        p = self._plans.get(key)
+        if p is None:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            p = self.dit.make_plan(shapes, mask)
+            self._plans[key] = p
+        return p
+
+    def _pyramid(self, x, n_down):
+        """get_pyramid_latent (:555-570): x [C,T,H,W] fp32 device -> list low..high."""
+        out = [x]
+        for _ in range(n_down):
+            C, T, H, W = x.shape
+            y = torch.empty(C, T, H // 2, W // 2, dtype=torch.float32, device=x.device)
+            ops.avgpool2(x, y, C * T, H, W, 1.0, self._round)
+            out.append(y)
+            x = y
+        return list(reversed(out))
+
+    def _history(self, clean, unit_index):
+        """:1159-1182 -> per stage list of clips [1,C,t,h,w] oldest -> newest (CFG duplicate is implicit)."""
+        res = []
+        for i_s in range(len(self.stages)):
+            stage_input = [clean[i_s][:, -1:]]
+            cur_stage, ptx = i_s, 1
+            while ptx < unit_index:
+                cur_stage = max(cur_stage - 1, 0)
+                if cur_stage == 0:
+                    break
+                ptx += 1
+                stage_input.append(clean[cur_stage][:, -ptx:clean[cur_stage].shape[1] - (ptx - 1)])
+            if cur_stage == 0 and ptx < unit_index:
+                stage_input.append(clean[0][:, :-ptx])
+            res.append([c.contiguous()[None] for c in reversed(stage_input)])
+        return res
+
+    @torch.no_grad()
+    def generate_one_unit(self, x, past, prompt_mask, pooled, num_inference_steps, is_first_frame):
+        """:706-788.  x: fp32 device latent [C,1,h0,w0] at stage-0 resolution.  Returns list of per-stage latents."""
+        outs = []
+        C = x.shape[0]
+        B = 2 if self.do_classifier_free_guidance else 1
+        for i_s in range(len(self.stages)):
+            self.scheduler.set_timesteps(num_inference_steps[i_s], i_s, device=None)
+            if i_s > 0:
+                h, w = x.shape[-2] * 2, x.shape[-1] * 2
+                ori_sigma = 1 - self.scheduler.ori_start_sigmas[i_s]
+                gamma = self.scheduler.config.gamma
+                alpha = 1 / (math.sqrt(1 + (1 / gamma)) * (1 - ori_sigma) + ori_sigma)
+                beta = alpha * (1 - ori_sigma) / math.sqrt(gamma)
+                noise = self.sample_block_noise(1, C, 1, h, w).to(self._device, torch.float32).contiguous()
+                xn = torch.empty(C, 1, h, w, dtype=torch.float32, device=self._device)
+                ops.renoise_upsample(x, noise, xn, C, h, w, alpha, beta, self._round)
+                x = xn
+            clips = past[i_s] + [x[None]]
+            shapes = [tuple(c.shape[2:]) for c in clips]
+            plan = self._plan(shapes, prompt_mask)
+            gs = self._guidance_scale if is_first_frame else self._video_guidance_scale
+            h, w = x.shape[-2], x.shape[-1]
+            for t in self.scheduler._timesteps_host:
+                tv = float(t)
+                if self._round:
+                    tv = float(torch.tensor(tv, dtype=torch.float64).to(torch.bfloat16))      # pipeline.py:750
+                vtok = self.dit.forward_tokens(plan, clips, [tv] * B, pooled, shared_clips=True)
+                ops.cfg_euler_step(vtok, vtok.stride(0), vtok.stride(1), x, C, h, w, gs, B == 2,
+                                   self.scheduler.dsigma(), self._round)
+            outs.append(x)
+        return outs
+
+    @torch.no_grad()
+    def generate(self, prompt=None, height=None, width=None, temp=1, num_inference_steps=28,
+                 video_num_inference_steps=28, guidance_scale=7.0, video_guidance_scale=7.0, min_guidance_scale=2.0,
+                 use_linear_guidance=False, alpha=0.5, negative_prompt=DEFAULT_NEGATIVE, num_images_per_prompt=1,
+                 generator=None, output_type="pil", save_memory=True, cpu_offloading=False, inference_multigpu=False,
+                 callback=None, prompt_embeds=None):
+        """:1006-1219.  `prompt_embeds=(embeds[1,Lt,C], mask[1,Lt], pooled[1,Cp], neg_embeds, neg_mask, neg_pooled)`
+        bypasses the text encoders (synthetic-prompt benchmark)."""
+        assert (temp - 1) % self.frame_per_unit == 0, "The frames should be divided by frame_per unit"
+        assert height % 64 == 0 and width % 64 == 0, "height/width must be multiples of 64 (8 VAE x 4 pyramid x 2 patch)"
+        n_st = len(self.stages)
+        if isinstance(num_inference_steps, int):
+            num_inference_steps = [num_inference_steps] * n_st
+        if isinstance(video_num_inference_steps, int):
+            video_num_inference_steps = [video_num_inference_steps] * n_st
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise RuntimeError("no text encoder loaded: pass prompt_embeds=(...) (synthetic prompts) or a text_encoder")
+            if isinstance(prompt, str):
+                prompt = prompt + ", hyper quality, Ultra HD, 8K"
+            else:
+                assert isinstance(prompt, list) and len(prompt) == 1, "batch size 1"
+                prompt = [p + ", hyper quality, Ultra HD, 8K" for p in prompt]
+            pe, pm, pp = self.text_encoder(prompt, self._device)
+            ne, nm, npool = self.text_encoder(negative_prompt or "", self._device)
+        else:
+            pe, pm, pp, ne, nm, npool = prompt_embeds
+        self._guidance_scale = guidance_scale
+        self._video_guidance_scale = video_guidance_scale
+        if use_linear_guidance:
+            guidance_scale_list = [max(guidance_scale - alpha * t_, min_guidance_scale) for t_ in range(temp)]
+        if self.do_classifier_free_guidance:
+            pe = torch.cat([ne, pe], dim=0)
+            pp = torch.cat([npool, pp], dim=0)
+            pm = torch.cat([nm, pm], dim=0)
+        self._round = (self.model_dtype == "bf16") and pe.dtype == torch.bfloat16
+        self.dit.encode_context(pe)
+        C = self.dit.w.out_cols // 4
+        latents = self.prepare_latents(1, C, temp, height, width, pe.dtype, self._device, generator)
+        x = latents[0].to(self._device, torch.float32).contiguous()                 # [C,T,H,W]
+        for _ in range(n_st - 1):                                                     # :1112-1116
+            Cc, T, H, W = x.shape
+            y = torch.empty(Cc, T, H // 2, W // 2, dtype=torch.float32, device=self._device)
+            ops.avgpool2(x, y, Cc * T, H, W, 2.0, self._round)
+            x = y
+        num_units = 1 + (temp - 1) // self.frame_per_unit
+        generated = []
+        for unit_index in range(num_units):
+            if callback:
+                callback(unit_index, num_units)
+            if use_linear_guidance:
+                self._guidance_scale = guidance_scale_list[unit_index]
+                self._video_guidance_scale = guidance_scale_list[unit_index]
+            if unit_index == 0:
+                past = [[] for _ in range(n_st)]
+                outs = self.generate_one_unit(x[:, :1].contiguous(), past, pm, pp, num_inference_steps, True)
+            else:
+                clean = self._pyramid(torch.cat(generated, dim=1), n_st - 1)
+                past = self._history(clean, unit_index)
+                outs = self.generate_one_unit(x[:, unit_index:unit_index + 1].contiguous(), past, pm, pp,
+                                              video_num_inference_steps, False)
+            generated.append(outs[-1])
+        gen = torch.cat(generated, dim=1)[None]                                      # [1,C,T,h,w] fp32
+        if output_type == "latent":
+            return gen.to(pe.dtype) if self._round else gen
+        return self.decode_latent(gen, save_memory=save_memory, inference_multigpu=inference_multigpu,
+                                  output_type=output_type)
+
+    @torch.no_grad()
+    def decode_latent(self, latents, save_memory=True, inference_multigpu=False, output_type="pil"):
+        """:1221-1243.  Returns list[PIL] (or uint8 [T,H,W,3] tensor for output_type='uint8')."""
+        if inference_multigpu and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+            return None
+        if self.vae is None:
+            raise RuntimeError("VAE not loaded")
+        z = latents.to(self._device, torch.float32).clone()
+        z[:, :, :1] = z[:, :, :1] / self.vae_scale_factor + self.vae_shift_factor
+        if z.shape[2] > 1:
+            z[:, :, 1:] = z[:, :, 1:] / self.vae_video_scale_factor + self.vae_video_shift_factor
+        if save_memory:
+            u8 = self.vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256)
+        else:
+            u8 = self.vae.decode_to_uint8(z, window_size=2, tile_sample_min_size=512)
+        if output_type == "uint8":
+            return u8
+        arr = u8.cpu().numpy()
+        from PIL import Image
+        return [Image.fromarray(a) for a in arr]
+
+    def generate_i2v(self, *a, **k):
+        raise NotImplementedError("generate_i2v needs the VAE encoder (scope table row V-4, config C4): next round")
+
+
+def _load_diffusers_dir(path):
+    """config.json + diffusion_pytorch_model.safetensors (pipeline.py:73,156)."""
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    sd = {}
+    for fn in sorted(os.listdir(path)):
+        if fn.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(path, fn)))
+    return sd, cfg
