@@ -69,6 +69,7 @@ typedef struct {
     int st, sh, sw, Cg, Hop, Wop, Cout_pitch;
     long long out_base_off;
     int flags; float out_scale;
+    int out_t_shift;         /* added to the output frame index, frames < 0 dropped (is_init_image drop, modeling_resnet.py:726) */
 } pf_conv_desc;
 int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
 
@@ -133,6 +134,32 @@ int pf_renoise_upsample(const float* xin, const float* noise, float* xout, int C
 /* pf_avgpool2: 2x2 mean * mul == F.interpolate(bilinear, 1/2) (pipeline.py:565, 1116) */
 int pf_avgpool2(const float* xin, float* xout, long long planes, int H, int W, float mul, int round_bf16,
                 pf_stream_t stream);
+
+
+/* ------------------------------------------------------------------ VAE decode helpers -----------
+ * Activations are channels-last bf16 frames [Hp][Wp][Cp]; `off`/`fs` give the element offset of the
+ * first interior pixel and the frame stride.  CausalGroupNorm (per-frame GroupNorm, eps 1e-6) + SiLU:
+ * modeling_causal_conv.py:36-43, modeling_resnet.py:127-141.  stats = double [T][C][2], zeroed by caller. */
+int pf_gn_stats(const void* x, double* stats, int T, int C, int Cp, int H, int W, int Hp, int Wp,
+                long long frame_stride, long long base_off, pf_stream_t stream);
+int pf_gn_apply(const void* x, void* y, const double* stats, const float* gamma, const float* beta, int T, int C,
+                int G, int H, int W, int Cp_in, int Hp_in, int Wp_in, long long fs_in, long long off_in, int Cp_out,
+                int Hp_out, int Wp_out, long long fs_out, long long off_out, float eps, int silu, pf_stream_t stream);
+/* row softmax of S (bf16, in place) * scale over the first n_valid columns, zero beyond (mid-block attention,
+ * diffusers Attention with upcast_softmax; modeling_block.py:413-427) */
+int pf_softmax_rows(void* S, int ld, int n_valid, int n_cols, int rows, float scale, pf_stream_t stream);
+/* latent z [C][T][H][W] fp32, frames t0..t0+nt, window (h0,w0,th,tw) -> channels-last bf16 with per-frame-class
+ * affine (frame 0: a0 z + b0, others a1 z + b1: decode_latent un-normalisation, pipeline.py:1226-1230) */
+int pf_latent_to_nhwc(const float* z, void* y, int C, int T, int H, int W, int t0, int nt, int h0, int w0, int th,
+                      int tw, int Cp, int Hp, int Wp, long long fs_out, long long off_out, float a0, float b0,
+                      float a1, float b1, pf_stream_t stream);
+/* blend_v / blend_h of tiled decode (modeling_causal_vae.py:397-407): tiles [T][H][W][Cp] bf16, b updated in place */
+int pf_blend_tiles(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb, int Cp, int extent, int vertical,
+                   pf_stream_t stream);
+/* crop [0:crop_h, 0:crop_w] of a decoded tile -> uint8 RGB frames at (y0, x0) of out [T][H][W][3]
+ * (pipeline.py:1238-1239) */
+int pf_to_uint8(const void* tile, void* out, int T, int Ht, int Wt, int Cp, int crop_h, int crop_w, int H, int W,
+                int y0, int x0, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ struct OutMap {              // where output row m / column-group g lands
     int Hop, Wop;            // padded output pitches
     long long base_off;      // element offset of output pixel (0,0,0) channel 0
     int Cout_pitch;          // channel pitch of the output buffer
+    int t_shift;             // added to the output frame index; negative frames are dropped
 };
 
 struct Args {
@@ -197,8 +198,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
             const int shw = p.om.sh * p.om.sw;
             const int pt = g / shw, g2 = g - pt * shw;
             const int ph = g2 / p.om.sw, pw = g2 - ph * p.om.sw;
+            const int tf = tt * p.om.st + pt + p.om.t_shift;
+            if (tf < 0) continue;
             coff = p.om.base_off +
-                   (((long long)(tt * p.om.st + pt) * p.om.Hop + (hh * p.om.sh + ph)) * p.om.Wop + (ww * p.om.sw + pw)) *
+                   (((long long)tf * p.om.Hop + (hh * p.om.sh + ph)) * p.om.Wop + (ww * p.om.sw + pw)) *
                        p.om.Cout_pitch + cc;
         } else {
             coff = (long long)b * p.sC + (long long)m * p.ldc + n;
@@ -267,7 +270,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     a.gelu_from = d->N; a.flags = d->flags; a.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     a.n_valid = d->n_valid > 0 ? d->n_valid : d->N;
     a.cg = ConvGeom{d->H, d->W_, d->Hp, d->Wp, d->Cin, d->kt, d->kh, d->kw, d->in_base_off};
-    a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch};
+    a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
     const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
     hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);

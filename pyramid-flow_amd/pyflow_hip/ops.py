@@ -12,13 +12,13 @@ from .lib import GemmDesc, AttnDesc, ConvDesc, check, ptr, stream, GEMM_GATE_RES
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
-         a_off=0, c_off=0, r_off=0, gate_off=0):
+         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0):
     """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res."""
     lib = L.load()
     esz_c = 4 if (flags & GEMM_OUT_F32) else 2
     d = GemmDesc()
     d.A = A.data_ptr() + 2 * a_off
-    d.W = W.data_ptr()
+    d.W = W.data_ptr() + 2 * w_off
     d.C = Cout.data_ptr() + esz_c * c_off
     d.bias = bias.data_ptr() if bias is not None else None
     d.res = (res.data_ptr() + 2 * r_off) if res is not None else None

@@ -264,14 +264,14 @@ class PyramidDiTForVideoGeneration:
             return None
         if self.vae is None:
             raise RuntimeError("VAE not loaded")
-        z = latents.to(self._device, torch.float32).clone()
-        z[:, :, :1] = z[:, :, :1] / self.vae_scale_factor + self.vae_shift_factor
-        if z.shape[2] > 1:
-            z[:, :, 1:] = z[:, :, 1:] / self.vae_video_scale_factor + self.vae_video_shift_factor
+        z = latents.to(self._device, torch.float32)
+        # un-normalisation (:1226-1230) is folded into the latent -> channels-last load of the decoder
+        aff = (1.0 / self.vae_scale_factor, self.vae_shift_factor,
+               1.0 / self.vae_video_scale_factor, self.vae_video_shift_factor)
         if save_memory:
-            u8 = self.vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256)
+            u8 = self.vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256, affine=aff)
         else:
-            u8 = self.vae.decode_to_uint8(z, window_size=2, tile_sample_min_size=512)
+            u8 = self.vae.decode_to_uint8(z, window_size=2, tile_sample_min_size=512, affine=aff)
         if output_type == "uint8":
             return u8
         arr = u8.cpu().numpy()

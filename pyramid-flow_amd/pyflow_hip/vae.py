@@ -1,0 +1,456 @@
+"""CausalVideoVAE decode on MI355X -- drop-in for video_vae/modeling_causal_vae.py:39-519 (decode side).
+
+Data layout (DESIGN.md "VAE data layout"): every activation is a channels-last bf16 buffer
+``[2 + Tmax][H+2][W+2][Cp]``: a one-pixel zero border (the conv's spatial padding, never written) and two
+leading temporal slots that hold the previous chunk's last two frames -- the reference's
+``cache_front_feat`` (modeling_causal_conv.py:128-143) -- or zeros for the first chunk (== the causal
+zero padding).  A CausalConv3d is then a pure implicit GEMM (pf_conv3d_bf16): rows = output pixels,
+K = 27*Cp, no bounds checks.  Temporal chunking streams the latent frame by frame exactly like
+``chunk_decode`` (:347-374); tiling (:468-519) loops the same program over latent windows and blends.
+Pixel-shuffle / depth-to-time rearranges (modeling_resnet.py:609-617, 716-729) are folded into the conv's
+store addressing (filter rows permuted at load time).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from . import ops
+from .lib import ConvDesc, check, stream, GEMM_GATE_RES
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class PBuf:
+    """padded channels-last activation with 2 temporal cache slots."""
+
+    def __init__(self, name, Tmax, H, W, Cc, device):
+        self.name, self.T, self.H, self.W, self.C = name, Tmax, H, W, Cc
+        self.Cp, self.Hp, self.Wp = _ru(Cc, 64), H + 2, W + 2
+        self.fs = self.Hp * self.Wp * self.Cp
+        self.t = torch.zeros((Tmax + 2) * self.fs, dtype=torch.bfloat16, device=device)
+        self.cur = 0          # frames valid in slots [2, 2+cur)
+
+    def off(self, slot):
+        return slot * self.fs + (self.Wp + 1) * self.Cp
+
+    def shift_cache(self):
+        """slots[0:2] <- last two of slots[0:2+cur]  (cache_front_feat update, causal_conv.py:132,143)."""
+        n = self.cur
+        fs = self.fs
+        if n >= 2:
+            self.t[0:2 * fs].copy_(self.t[n * fs:(n + 2) * fs])
+        elif n == 1:
+            self.t[0:fs].copy_(self.t[fs:2 * fs])
+            self.t[fs:2 * fs].copy_(self.t[2 * fs:3 * fs])
+
+    def reset(self):
+        self.t[:2 * self.fs].zero_()
+        self.cur = 0
+
+
+class ConvW:
+    """filters repacked to [Np][taps][Cp_in] bf16 (+fp32 bias), rows permuted for the upsampling stores."""
+
+    def __init__(self, w, b, device, groups=1):
+        co, ci, kt, kh, kw = w.shape
+        self.kt, self.kh, self.kw = kt, kh, kw
+        cp = _ru(ci, 64)
+        cg = co // groups
+        # output column n = g*cg + c  <-  original filter c*groups + g
+        idx = torch.arange(co).view(cg, groups).t().reshape(-1)
+        w = w[idx]
+        b = b[idx]
+        n_valid = co
+        Np = _ru(co, 128)
+        wp = torch.zeros(Np, kt * kh * kw, cp, dtype=torch.float32)
+        wp[:co, :, :ci] = w.permute(0, 2, 3, 4, 1).reshape(co, kt * kh * kw, ci)
+        bp = torch.zeros(Np, dtype=torch.float32)
+        bp[:co] = b
+        self.w = wp.reshape(Np, -1).to(device=device, dtype=torch.bfloat16).contiguous()
+        self.b = bp.to(device)
+        self.N, self.n_valid, self.Cg, self.groups, self.cin_p = Np, n_valid, cg, groups, cp
+
+
+def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None):
+    """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple."""
+    lib = L.load()
+    d = ConvDesc()
+    d.X = src.t.data_ptr()
+    d.W = cw.w.data_ptr()
+    d.bias = cw.b.data_ptr()
+    d.T, d.H, d.W_ = Tc, src.H, src.W
+    d.Hp, d.Wp, d.Cin = src.Hp, src.Wp, src.Cp
+    d.kt, d.kh, d.kw = cw.kt, cw.kh, cw.kw
+    assert cw.cin_p == src.Cp
+    if cw.kt == 3:
+        d.in_base_off = 0
+    else:
+        d.in_base_off = src.off(2)
+    d.N, d.n_valid = cw.N, cw.n_valid
+    d.st, d.sh, d.sw, d.Cg = st, sh, sw, cw.Cg
+    if dst_raw is not None:
+        t, Ht, Wt, Cp, frame0 = dst_raw
+        d.Y = t.data_ptr()
+        d.Hop, d.Wop, d.Cout_pitch = Ht, Wt, Cp
+        d.out_base_off = frame0 * Ht * Wt * Cp
+        d.n_valid = Cp
+        d.Cg = Cp
+    else:
+        d.Y = dst.t.data_ptr()
+        d.Hop, d.Wop, d.Cout_pitch = dst.Hp, dst.Wp, dst.Cp
+        d.out_base_off = dst.off(2)
+        assert dst.H == src.H * sh and dst.W == src.W * sw
+    d.flags = GEMM_GATE_RES if res is not None else 0
+    d.res = res.t.data_ptr() if res is not None else None
+    if res is not None:
+        assert (res.Hp, res.Wp, res.Cp) == (dst.Hp, dst.Wp, dst.Cp)
+    d.out_scale = 1.0
+    d.out_t_shift = t_shift
+    check(lib.pf_conv3d_bf16(C.byref(d), stream()))
+    if dst is not None:
+        dst.cur = Tc * st + t_shift
+
+
+class _TileProgram:
+    """all buffers + the layer sequence for one latent tile geometry (th x tw)."""
+
+    def __init__(self, vae, th, tw, t_first, t_later):
+        self.vae, self.th, self.tw = vae, th, tw
+        self.bufs = {}
+        self.dev = vae.dev
+        cfg = vae.cfg
+        # frames per chunk at each temporal level (first chunk / later chunks)
+        self.tmax = [max(t_first, t_later)]
+        tf_, tl = t_first, t_later
+        for up in cfg["temporal_up_sample"]:
+            if up:
+                tf_, tl = 2 * tf_ - 1, 2 * tl
+                self.tmax.append(max(tf_, tl))
+        self.stats = torch.zeros(max(self.tmax) * 512 * 2, dtype=torch.float64, device=self.dev)
+        n = th * tw
+        ca = vae.attn_pitch
+        npad = _ru(n, 128)
+        self.n_tok, self.npad = n, npad
+        tm = self.tmax[0]
+        z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.dev)  # noqa: E731
+        self.a_x, self.a_q, self.a_k, self.a_o = z(tm, npad, ca), z(tm, npad, ca), z(tm, npad, ca), z(tm, npad, ca)
+        self.a_vt = z(ca, npad)
+        self.a_s = z(npad, npad)
+
+    def buf(self, name, level_t, H, W, Cc):
+        b = self.bufs.get(name)
+        if b is None:
+            b = PBuf(name, self.tmax[level_t], H, W, Cc, self.dev)
+            self.bufs[name] = b
+        return b
+
+    def reset(self):
+        for b in self.bufs.values():
+            b.reset()
+
+    # ---- layer helpers -------------------------------------------------------------------------
+    def gn(self, src, dst, name, silu=True, dst_raw=None):
+        v = self.vae
+        g, bt = v.norms[name]
+        Tc = src.cur
+        st = self.stats[:Tc * src.C * 2]
+        st.zero_()
+        lib = L.load()
+        check(lib.pf_gn_stats(C.c_void_p(src.t.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int(Tc), C.c_int(src.C),
+                              C.c_int(src.Cp), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Hp), C.c_int(src.Wp),
+                              C.c_longlong(src.fs), C.c_longlong(src.off(2)), stream()))
+        if dst_raw is None:
+            args = (dst.t.data_ptr(), dst.Cp, dst.Hp, dst.Wp, dst.fs, dst.off(2))
+            dst.cur = Tc
+        else:
+            t, cp = dst_raw
+            args = (t.data_ptr(), cp, src.H, src.W, t.stride(0), 0)
+        check(lib.pf_gn_apply(C.c_void_p(src.t.data_ptr()), C.c_void_p(args[0]), C.c_void_p(st.data_ptr()),
+                              C.c_void_p(g.data_ptr()), C.c_void_p(bt.data_ptr()), C.c_int(Tc), C.c_int(src.C),
+                              C.c_int(v.groups), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Cp), C.c_int(src.Hp),
+                              C.c_int(src.Wp), C.c_longlong(src.fs), C.c_longlong(src.off(2)), C.c_int(args[1]),
+                              C.c_int(args[2]), C.c_int(args[3]), C.c_longlong(args[4]), C.c_longlong(args[5]),
+                              C.c_float(1e-6), C.c_int(int(silu)), stream()))
+
+    def resnet(self, x, p, lvl, out_name, cout):
+        """CausalResnetBlock3D.forward (modeling_resnet.py:115-150)."""
+        v = self.vae
+        Tc = x.cur
+        n1 = self.buf(p + "n1", lvl, x.H, x.W, x.C)
+        self.gn(x, n1, p + "norm1")
+        h = self.buf(p + "h", lvl, x.H, x.W, cout)
+        conv(n1, h, v.convs[p + "conv1"], Tc)
+        n1.shift_cache()
+        n2 = self.buf(p + "n2", lvl, x.H, x.W, cout)
+        self.gn(h, n2, p + "norm2")
+        res = x
+        if (p + "conv_shortcut") in v.convs:
+            res = self.buf(p + "sc", lvl, x.H, x.W, cout)
+            conv(x, res, v.convs[p + "conv_shortcut"], Tc)
+        out = self.buf(out_name, lvl, x.H, x.W, cout)
+        conv(n2, out, v.convs[p + "conv2"], Tc, res=res)
+        n2.shift_cache()
+        return out
+
+    def mid_attention(self, x, out_name):
+        """per-frame 1-head attention (modeling_block.py:456-460 + diffusers Attention, deprecated-attn-block form)."""
+        v = self.vae
+        Tc, n, npad, ca = x.cur, self.n_tok, self.npad, v.attn_pitch
+        self.gn(x, None, "decoder.mid_block.attentions.0.group_norm", silu=False, dst_raw=(self.a_x, ca))
+        wq, bq = v.attn["to_q"]
+        wk, bk = v.attn["to_k"]
+        wv, bv = v.attn["to_v"]
+        wo, bo = v.attn["to_out.0"]
+        ops.gemm(self.a_x, wq, self.a_q, npad, ca, ca, ca, ca, ca, bias=bq, batch=Tc, strideA=npad * ca, strideC=npad * ca)
+        ops.gemm(self.a_x, wk, self.a_k, npad, ca, ca, ca, ca, ca, bias=bk, batch=Tc, strideA=npad * ca, strideC=npad * ca)
+        out = self.buf(out_name, 0, x.H, x.W, x.C)
+        for f in range(Tc):
+            fo = f * npad * ca
+            # V^T = Wv . X^T  (bias folded into the PV epilogue: rows of P sum to 1)
+            ops.gemm(wv, self.a_x, self.a_vt, ca, npad, ca, ca, ca, npad, c_off=0, a_off=0, w_off=fo)
+            ops.gemm(self.a_q, self.a_k, self.a_s, n, npad, ca, ca, ca, npad, a_off=fo, w_off=fo)
+            check(L.load().pf_softmax_rows(C.c_void_p(self.a_s.data_ptr()), C.c_int(npad), C.c_int(n), C.c_int(npad),
+                                           C.c_int(n), C.c_float(v.attn_scale), stream()))
+            ops.gemm(self.a_s, self.a_vt, self.a_o, n, ca, npad, npad, npad, ca, bias=bv, c_off=fo)
+        # to_out + residual, written into the padded image (1x1x1 conv form, A un-padded)
+        lib = L.load()
+        for f in range(Tc):
+            d = ConvDesc()
+            d.X = self.a_o.data_ptr() + 2 * f * npad * ca
+            d.W, d.bias = wo.data_ptr(), bo.data_ptr()
+            d.T, d.H, d.W_ = 1, x.H, x.W
+            d.Hp, d.Wp, d.Cin = x.H, x.W, ca
+            d.kt = d.kh = d.kw = 1
+            d.in_base_off = 0
+            d.N, d.n_valid = wo.shape[0], x.C
+            d.st = d.sh = d.sw = 1
+            d.Cg = wo.shape[0]
+            d.Y = out.t.data_ptr()
+            d.res = x.t.data_ptr()
+            d.Hop, d.Wop, d.Cout_pitch = out.Hp, out.Wp, out.Cp
+            d.out_base_off = out.off(2 + f)
+            d.flags, d.out_scale, d.out_t_shift = GEMM_GATE_RES, 1.0, 0
+            check(lib.pf_conv3d_bf16(C.byref(d), stream()))
+        out.cur = Tc
+        return out
+
+    # ---- one chunk through post_quant_conv + decoder (modeling_enc_dec.py:302-366) -------------------
+    def run_chunk(self, z, t0, nt, h0, w0, first, out_tile, out_frame0, affine):
+        v = self.vae
+        cfg = v.cfg
+        th, tw = self.th, self.tw
+        lat = cfg["latent_channels"]
+        zb = self.buf("z", 0, th, tw, lat)
+        lib = L.load()
+        Zc, ZT, ZH, ZW = z.shape
+        check(lib.pf_latent_to_nhwc(C.c_void_p(z.data_ptr()), C.c_void_p(zb.t.data_ptr()), C.c_int(Zc), C.c_int(ZT),
+                                    C.c_int(ZH), C.c_int(ZW), C.c_int(t0), C.c_int(nt), C.c_int(h0), C.c_int(w0),
+                                    C.c_int(th), C.c_int(tw), C.c_int(zb.Cp), C.c_int(zb.Hp), C.c_int(zb.Wp),
+                                    C.c_longlong(zb.fs), C.c_longlong(zb.off(2)), C.c_float(affine[0]), C.c_float(affine[1]),
+                                    C.c_float(affine[2]), C.c_float(affine[3]), stream()))
+        zb.cur = nt
+        pq = self.buf("pq", 0, th, tw, lat)
+        conv(zb, pq, v.convs["post_quant_conv"], nt)
+        top = cfg["block_out_channels"][-1]
+        x = self.buf("conv_in", 0, th, tw, top)
+        conv(pq, x, v.convs["decoder.conv_in"], nt)
+        pq.shift_cache()
+        x = self.resnet(x, "decoder.mid_block.resnets.0.", 0, "mid.r0", top)
+        x = self.mid_attention(x, "mid.attn")
+        x = self.resnet(x, "decoder.mid_block.resnets.1.", 0, "mid.r1", top)
+        rev = list(reversed(cfg["block_out_channels"]))
+        lvl = 0
+        for i, co in enumerate(rev):
+            p = f"decoder.up_blocks.{i}."
+            for j in range(cfg["layers_per_block"][i]):
+                x = self.resnet(x, p + f"resnets.{j}.", lvl, f"up{i}.r{j}", co)
+            if cfg["spatial_up_sample"][i]:
+                y = self.buf(f"up{i}.sp", lvl, x.H * 2, x.W * 2, co)
+                conv(x, y, v.convs[p + "upsamplers.0.conv"], x.cur, sh=2, sw=2)
+                x.shift_cache()
+                x = y
+            if cfg["temporal_up_sample"][i]:
+                y = self.buf(f"up{i}.tp", lvl + 1, x.H, x.W, co)
+                conv(x, y, v.convs[p + "temporal_upsamplers.0.conv"], x.cur, st=2, t_shift=-1 if first else 0)
+                x.shift_cache()
+                x = y
+                lvl += 1
+        n = self.buf("norm_out", lvl, x.H, x.W, x.C)
+        self.gn(x, n, "decoder.conv_norm_out")
+        conv(n, None, v.convs["decoder.conv_out"], n.cur, dst_raw=(out_tile, x.H, x.W, 8, out_frame0))
+        nf = n.cur
+        n.shift_cache()
+        return nf
+
+
+class DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class CausalVideoVAE:
+    """decode(z, is_init_image=True, temporal_chunk=False, return_dict=True, window_size=2, tile_sample_min_size=256)
+    -> DecoderOutput(sample [B,3,T,H,W]);  enable_tiling()/disable_tiling()  (modeling_causal_vae.py:183-196, 376-395)."""
+
+    def __init__(self, state_dict, cfg=None, device="cuda"):
+        from . import synth
+        self.dev = torch.device(device)
+        cfg = dict(cfg or synth.VAE_DEFAULT)
+        if "decoder_block_out_channels" in cfg:      # reference-style config (causal_vae.py:73-116)
+            cfg = dict(latent_channels=cfg.get("decoder_in_channels", 4),
+                       block_out_channels=tuple(cfg["decoder_block_out_channels"]),
+                       layers_per_block=tuple(cfg.get("decoder_layers_per_block", (3, 3, 3, 3))),
+                       spatial_up_sample=tuple(cfg.get("decoder_spatial_up_sample", (True, True, True, False))),
+                       temporal_up_sample=tuple(cfg.get("decoder_temporal_up_sample", (True, True, True, False))),
+                       out_channels=cfg.get("decoder_out_channels", 3),
+                       norm_num_groups=cfg.get("decoder_norm_num_groups", 32))
+        self.cfg = cfg
+        self.groups = cfg["norm_num_groups"]
+        self.use_tiling = False
+        self.downsample_scale = 8
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items()
+              if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+        self.convs, self.norms, self.attn = {}, {}, {}
+        for k in sd:
+            if k.endswith(".conv.weight"):
+                name = k[:-len(".conv.weight")]
+                groups = 4 if ".upsamplers." in name else (2 if ".temporal_upsamplers." in name else 1)
+                self.convs[name] = ConvW(sd[k], sd[name + ".conv.bias"], self.dev, groups)
+            elif k.endswith(".weight") and sd[k].ndim == 1:
+                name = k[:-len(".weight")]
+                self.norms[name] = (sd[k].to(self.dev), sd[name + ".bias"].to(self.dev))
+        top = cfg["block_out_channels"][-1]
+        self.attn_pitch = ca = _ru(top, 128)
+        self.attn_scale = top ** -0.5
+        a = "decoder.mid_block.attentions.0."
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            w = torch.zeros(ca, ca)
+            w[:top, :top] = sd[a + n + ".weight"]
+            b = torch.zeros(ca)
+            b[:top] = sd[a + n + ".bias"]
+            self.attn[n] = (w.to(self.dev, torch.bfloat16).contiguous(), b.to(self.dev))
+        self._programs = {}
+
+    def enable_tiling(self, use_tiling=True):
+        self.use_tiling = use_tiling
+
+    def disable_tiling(self):
+        self.enable_tiling(False)
+
+    # ---- chunk schedule of chunk_decode (:347-374)
+    @staticmethod
+    def chunk_sizes(num_frames, window_size, temporal_chunk):
+        if not temporal_chunk:
+            return [num_frames]
+        init = min(window_size + 1, num_frames)
+        sizes = [init]
+        fid = init
+        for _ in range((num_frames - init) // window_size):
+            sizes.append(window_size)
+            fid += window_size
+        if fid < num_frames:
+            sizes.append(num_frames - fid)
+        return sizes
+
+    def _program(self, th, tw, sizes):
+        key = (th, tw, sizes[0], max(sizes[1:] or [sizes[0]]))
+        p = self._programs.get(key)
+        if p is None:
+            p = _TileProgram(self, th, tw, key[2], key[3])
+            self._programs[key] = p
+        return p
+
+    def _decode_tile(self, z, h0, w0, th, tw, sizes, affine):
+        """-> bf16 [T_out, 8 th, 8 tw, 8] (channels 0..2 valid)."""
+        T = z.shape[1]
+        n_t = sum(self.cfg["temporal_up_sample"])
+        f = 2 ** n_t
+        T_out = 1 + f * (T - 1)
+        s = 2 ** sum(self.cfg["spatial_up_sample"])
+        out = torch.empty(T_out, th * s, tw * s, 8, dtype=torch.bfloat16, device=self.dev)
+        prog = self._program(th, tw, sizes)
+        prog.reset()
+        t0, fo = 0, 0
+        for ci, nt in enumerate(sizes):
+            fo += prog.run_chunk(z, t0, nt, h0, w0, ci == 0, out, fo, affine)
+            t0 += nt
+        assert fo == T_out, (fo, T_out)
+        return out
+
+    @torch.no_grad()
+    def decode_tiles(self, z, temporal_chunk, window_size, tile_sample_min_size, affine=(1.0, 0.0, 1.0, 0.0)):
+        """z [1,C,T,h,w] fp32 -> (tiles grid, geometry) following decode/tiled_decode (:376-395, 468-519)."""
+        assert z.shape[0] == 1, "batch size 1"
+        z = z[0].to(self.dev, torch.float32).contiguous()
+        Cc, T, H, W = z.shape
+        tl = int(tile_sample_min_size / self.downsample_scale)
+        sizes = tuple(self.chunk_sizes(T, window_size, temporal_chunk))
+        if not (self.use_tiling and (W > tl or H > tl)):
+            return [[self._decode_tile(z, 0, 0, H, W, sizes, affine)]], None
+        overlap = int(tl * 0.75)
+        blend = int(tile_sample_min_size * 0.25)
+        limit = tile_sample_min_size - blend
+        rows = []
+        for i in range(0, H, overlap):
+            rows.append([self._decode_tile(z, i, j, min(tl, H - i), min(tl, W - j), sizes, affine)
+                         for j in range(0, W, overlap)])
+        lib = L.load()
+        for i, row in enumerate(rows):
+            for j, tile in enumerate(row):
+                Tt, Hb, Wb, _ = tile.shape
+                if i > 0:
+                    a = rows[i - 1][j]
+                    check(lib.pf_blend_tiles(C.c_void_p(a.data_ptr()), C.c_void_p(tile.data_ptr()), C.c_int(Tt),
+                                             C.c_int(a.shape[1]), C.c_int(a.shape[2]), C.c_int(Hb), C.c_int(Wb), C.c_int(8),
+                                             C.c_int(blend), C.c_int(1), stream()))
+                if j > 0:
+                    a = row[j - 1]
+                    check(lib.pf_blend_tiles(C.c_void_p(a.data_ptr()), C.c_void_p(tile.data_ptr()), C.c_int(Tt),
+                                             C.c_int(a.shape[1]), C.c_int(a.shape[2]), C.c_int(Hb), C.c_int(Wb), C.c_int(8),
+                                             C.c_int(blend), C.c_int(0), stream()))
+        return rows, limit
+
+    @torch.no_grad()
+    def decode_to_uint8(self, z, window_size=1, tile_sample_min_size=256, temporal_chunk=True, affine=(1.0, 0.0, 1.0, 0.0)):
+        """fused decode + (x*127.5+127.5).clamp.byte -> uint8 [T,H,W,3] on device (pipeline.py:1234-1240)."""
+        rows, limit = self.decode_tiles(z, temporal_chunk, window_size, tile_sample_min_size, affine)
+        lib = L.load()
+        T_out = rows[0][0].shape[0]
+        if limit is None:
+            t = rows[0][0]
+            H, W = t.shape[1], t.shape[2]
+            out = torch.empty(T_out, H, W, 3, dtype=torch.uint8, device=self.dev)
+            check(lib.pf_to_uint8(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(T_out), C.c_int(H), C.c_int(W),
+                                  C.c_int(8), C.c_int(H), C.c_int(W), C.c_int(H), C.c_int(W), C.c_int(0), C.c_int(0), stream()))
+            return out
+        hs = [min(r[0].shape[1], limit) for r in rows]
+        ws = [min(t.shape[2], limit) for t in rows[0]]
+        H, W = sum(hs), sum(ws)
+        out = torch.empty(T_out, H, W, 3, dtype=torch.uint8, device=self.dev)
+        y0 = 0
+        for i, row in enumerate(rows):
+            x0 = 0
+            for j, t in enumerate(row):
+                check(lib.pf_to_uint8(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(T_out), C.c_int(t.shape[1]),
+                                      C.c_int(t.shape[2]), C.c_int(8), C.c_int(hs[i]), C.c_int(ws[j]), C.c_int(H), C.c_int(W),
+                                      C.c_int(y0), C.c_int(x0), stream()))
+                x0 += ws[j]
+            y0 += hs[i]
+        return out
+
+    @torch.no_grad()
+    def decode(self, z, is_init_image=True, temporal_chunk=False, return_dict=True, window_size=2, tile_sample_min_size=256):
+        assert is_init_image, "inference decode always starts at the first frame"
+        rows, limit = self.decode_tiles(z, temporal_chunk, window_size, tile_sample_min_size)
+        if limit is None:
+            img = rows[0][0][..., :3]
+        else:
+            img = torch.cat([torch.cat([t[:, :limit, :limit, :3] for t in row], dim=2) for row in rows], dim=1)
+        sample = img.permute(3, 0, 1, 2)[None].contiguous()          # [1,3,T,H,W] (layout plumbing only)
+        if not return_dict:
+            return (sample,)
+        return DecoderOutput(sample)

@@ -1,0 +1,63 @@
+"""GPU parity of the whole sampler: generate() latents vs the committed reference trajectory (fixture produced by
+the UNMODIFIED reference's generate()) and vs the CPU oracle; uint8 frames vs the oracle decode.
+Tolerance: trajectory rel-L2 <= 5e-2 on latents."""
+import os
+
+import pytest
+import torch
+
+from util import rel_l2, round_sd
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "generate_tiny_latents.pt")
+
+
+def _pipe(g):
+    from pyflow_hip import synth
+    from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
+    from oracle.ref_harness import NoiseStream
+    dsd = round_sd(synth.random_state_dict(synth.flux_param_shapes(g["dit_cfg"]), seed=g["dit_weight_seed"], std=0.05, lively=True))
+    vsd = round_sd(synth.random_state_dict(synth.vae_decoder_param_shapes(g["vae_cfg"]), seed=g["vae_weight_seed"], std=0.05, lively=True))
+    pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=g["dit_cfg"], vae_state_dict=vsd,
+                                        vae_config=g["vae_cfg"], model_name="pyramid_flux")
+    pipe.block_noise_fn = NoiseStream(g["noise_seed"]).block_noise
+    return pipe, dsd, vsd
+
+
+def _embeds(g):
+    e, m, p = g["prompt_embeds"], g["prompt_mask"], g["pooled"]
+    return (e[1:2], m[1:2], p[1:2], e[0:1], m[0:1], p[0:1])
+
+
+def test_generate_latents_vs_reference_fixture():
+    g = torch.load(GOLD)
+    pipe, _, _ = _pipe(g)
+    lat = pipe.generate(prompt_embeds=_embeds(g), height=g["height"], width=g["width"], temp=g["temp"],
+                        num_inference_steps=g["steps"], video_num_inference_steps=g["video_steps"],
+                        guidance_scale=g["guidance"], video_guidance_scale=g["video_guidance"],
+                        generator=torch.Generator().manual_seed(g["latent_seed"]), output_type="latent")
+    assert lat.shape == g["latents"].shape
+    err = rel_l2(lat.float().cpu(), g["latents"])
+    print("trajectory rel-L2 vs reference fixture:", err)
+    assert err < 5e-2
+
+
+def test_generate_frames_vs_oracle():
+    from oracle.pipeline_oracle import decode_latents
+    g = torch.load(GOLD)
+    pipe, dsd, vsd = _pipe(g)
+    pipe.vae.enable_tiling()
+    frames = pipe.generate(prompt_embeds=_embeds(g), height=g["height"], width=g["width"], temp=g["temp"],
+                           num_inference_steps=g["steps"], video_num_inference_steps=g["video_steps"],
+                           guidance_scale=g["guidance"], video_guidance_scale=g["video_guidance"],
+                           generator=torch.Generator().manual_seed(g["latent_seed"]), output_type="uint8")
+    cfg = g["vae_cfg"]
+    ocfg = dict(decoder_block_out_channels=cfg["block_out_channels"], decoder_layers_per_block=cfg["layers_per_block"],
+                decoder_spatial_up_sample=cfg["spatial_up_sample"], decoder_temporal_up_sample=cfg["temporal_up_sample"])
+    ref_u8, _ = decode_latents(vsd, ocfg, g["latents"], use_tiling=True, tile_sample_min_size=256)
+    assert frames.shape == ref_u8.shape == (1 + 8 * (g["temp"] - 1), g["height"], g["width"], 3)
+    diff = (frames.cpu().int() - ref_u8.int()).abs().float()
+    mse = (diff ** 2).mean().item()
+    psnr = 10 * torch.log10(torch.tensor(255.0 ** 2 / max(mse, 1e-9))).item()
+    print("PSNR vs oracle frames:", psnr)
+    assert psnr >= 35.0
