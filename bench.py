@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of BASELINE.json: video frames/s (whole node) for 768p (768x1280) 241-frame
+text-to-video sampling with the miniFLUX pyramid DiT + CausalVideoVAE decode, synthetic prompts and random-init
+weights of the released architecture.
+
+A "step" = one complete video: generate() -> uint8 frames resident on the device (text encoding excluded, as in
+SURVEY 8d).  python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
+N > 1 (round 1): independent replicas, one video per rank ("weak"); sequence parallelism is the next row.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (height, width, temp, steps_first, steps_video)
+    "c3_768p_241f": (768, 1280, 31, [20, 20, 20], [10, 10, 10]),
+    "c2_384p_121f": (384, 640, 16, [20, 20, 20], [10, 10, 10]),
+    "smoke_128p_17f": (128, 192, 3, [4, 4, 4], [2, 2, 2]),
+}
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def build_pipeline(device, tiny=False):
+    from pyflow_hip import synth
+    from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
+    dcfg = synth.TINY_FLUX if tiny else synth.MINIFLUX
+    vcfg = synth.TINY_VAE if tiny else synth.VAE_DEFAULT
+    g = torch.Generator(device=device).manual_seed(1234)
+
+    def rand_sd(shapes):
+        # N(0, 0.02^2) matrices, norm gains 1, biases 0, generated on the device
+        sd = {}
+        for k, shp in shapes.items():
+            if len(shp) == 1:
+                sd[k] = torch.ones(shp, device=device) if k.endswith(".weight") else torch.zeros(shp, device=device)
+            else:
+                sd[k] = torch.randn(shp, generator=g, device=device) * 0.02
+        return sd
+    dsd = rand_sd(synth.flux_param_shapes(dcfg))
+    vsd = rand_sd(synth.vae_decoder_param_shapes(vcfg))
+    pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=dcfg, vae_state_dict=vsd, vae_config=vcfg,
+                                        model_name="pyramid_flux", model_dtype="bf16", device=device)
+    pipe.vae.enable_tiling()                      # reference inference setup (inference_multigpu.py:52-55)
+    return pipe, dcfg, dsd
+
+
+def synthetic_prompt(dcfg, device):
+    g = torch.Generator().manual_seed(1235)
+    Lt = 128
+    e = torch.randn(2, Lt, dcfg["joint_attention_dim"], generator=g).to(torch.bfloat16)
+    p = torch.randn(2, dcfg["pooled_projection_dim"], generator=g).to(torch.bfloat16)
+    m = torch.zeros(2, Lt, dtype=torch.long)
+    m[0, :40] = 1       # negative prompt
+    m[1, :96] = 1       # positive prompt
+    return (e[1:2], m[1:2], p[1:2], e[0:1], m[0:1], p[0:1])
+
+
+class SampledProfiler:
+    """turns the per-launch HIP-event profiler on for every `period`-th DiT forward of the timed region."""
+
+    def __init__(self, pipe, period):
+        from pyflow_hip import ops
+        self.prof = ops.PROFILER
+        self.count = 0
+        self.period = period
+        eng = pipe.dit
+        orig = eng.forward_tokens
+
+        def wrapped(*a, **k):
+            self.prof.enabled = self.active and (self.count % self.period == 0)
+            self.count += 1
+            try:
+                return orig(*a, **k)
+            finally:
+                self.prof.enabled = False
+        eng.forward_tokens = wrapped
+        self.active = False
+
+
+def cpu_baseline(dcfg, dsd, threads):
+    """reference path (CPU fp32 oracle restatement, kind 'port') on a bounded sample: ONE full-width miniFLUX
+    denoise forward at the (unit 1, stage 0) sequence (L = 608, CFG batch 2), extrapolated to the whole 241-frame
+    job by the dense-FLOP ratio of SURVEY 8d (50.67 PFLOP DiT; VAE and host loop not added -> optimistic for the CPU)."""
+    from oracle.flux_oracle import flux_forward
+    torch.set_num_threads(threads)
+    sd = {k: v.float().cpu() for k, v in dsd.items()}
+    g = torch.Generator().manual_seed(9)
+    clips = [torch.randn(2, 16, 1, 24, 40, generator=g), torch.randn(2, 16, 1, 24, 40, generator=g)]
+    enc = torch.randn(2, 128, dcfg["joint_attention_dim"], generator=g)
+    mask = torch.zeros(2, 128, dtype=torch.long)
+    mask[0, :40] = 1
+    mask[1, :96] = 1
+    pooled = torch.randn(2, dcfg["pooled_projection_dim"], generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        flux_forward(sd, dcfg, clips, enc, mask, pooled, torch.tensor([900.0, 900.0]))
+    dt = time.time() - t0
+    d = dcfg["num_attention_heads"] * dcfg["attention_head_dim"]
+    L, Lt, B = 608, 128, 2
+    gemm = 2 * B * (dcfg["num_layers"] * 12 * d * d * L * 2 / 2 * 1.0 + dcfg["num_single_layers"] * 12 * d * d * L)
+    gemm = 2 * B * L * 12 * d * d * (dcfg["num_layers"] + dcfg["num_single_layers"])
+    attn = 4 * B * L * L * d * (dcfg["num_layers"] + dcfg["num_single_layers"])
+    sample_flops = gemm + attn
+    total_dense = 50.67e15
+    est_seconds = dt * total_dense / sample_flops
+    return dict(value=241.0 / est_seconds, unit="frames/s", cores=threads, kind="port",
+                sample=f"1 oracle DiT forward (full miniFLUX width, L=608, B=2, {sample_flops / 1e12:.2f} TFLOP) in "
+                       f"{dt:.1f} s = {sample_flops / dt / 1e12:.2f} TFLOP/s fp32; extrapolated to the 50.67 PFLOP dense DiT "
+                       "work of one 241-frame video (VAE decode not added)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--workload", default="c3_768p_241f", choices=list(WORKLOADS))
+    ap.add_argument("--tiny-model", action="store_true", help="tiny random model (plumbing check, not a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-period", type=int, default=7)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+
+    H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
+    pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model)
+    embeds = synthetic_prompt(dcfg, device)
+    sp = SampledProfiler(pipe, args.profile_period)
+    frames_per_video = 1 + 8 * (temp - 1)
+
+    def one_video(seed):
+        return pipe.generate(prompt_embeds=embeds, height=H, width=W, temp=temp, num_inference_steps=steps1,
+                             video_num_inference_steps=stepsv, guidance_scale=7.0, video_guidance_scale=5.0,
+                             generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
+
+    # lazy code-object loading / first allocations are initialisation, not a step
+    pipe.generate(prompt_embeds=embeds, height=64, width=64, temp=2, num_inference_steps=[1, 1, 1],
+                  video_num_inference_steps=[1, 1, 1], guidance_scale=7.0, video_guidance_scale=5.0,
+                  generator=torch.Generator().manual_seed(0), output_type="uint8")
+    for i in range(args.warmup):
+        one_video(100 + i)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    sp.active = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_video(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    sp.active = False
+    assert out.shape == (frames_per_video, H, W, 3) and out.dtype == torch.uint8
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+    from pyflow_hip import ops
+    summ = ops.PROFILER.summary()
+    roof = None
+    extra = {}
+    for name, s in summ.items():
+        if s["ms_total"] <= 0:
+            continue
+        tf = s["work_total"] / (s["ms_total"] * 1e-3) / 1e12
+        rec = dict(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                   frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None, kernel=name, launches_timed=s["launches"],
+                   avg_launch_ms=round(s["ms_total"] / s["launches"], 4))
+        if name == "gemm":
+            roof = rec
+        else:
+            extra[name] = rec
+    value = frames_per_video * args.steps * world / dt
+    res = {
+        "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling",
+        "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: miniFLUX pyramid DiT (1.97 B params, 8+16 blocks, d=1920) + CausalVideoVAE "
+                               f"tiled(256)/chunked(1) decode, {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
+                               "CFG 7.0/5.0, random-init weights, synthetic prompt embeddings"
+                               + (" [TINY MODEL: plumbing only]" if args.tiny_model else ""),
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one video per GPU)"},
+        "roofline": roof,
+        "roofline_other_kernels": extra,
+    }
+    if not args.no_cpu_baseline and world == 1 and not args.tiny_model:
+        res["cpu_baseline"] = cpu_baseline(dcfg, dsd, os.cpu_count() or 1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,10 +18,21 @@ from .scheduler_oracle import SchedulerOracle
 from .vae_oracle import vae_decode, to_uint8_frames
 
 
+# scale_tril that torch's MultivariateNormal(zeros(4), (1+g)I - g 11^T) evaluates for the default g = 1/3 in
+# fp32 (the covariance is singular, so the last pivot is pure round-off and the PositiveDefinite validation of
+# the distribution is CPU-dependent: pinned here as constants; tests/test_oracle_vs_reference.py checks them
+# against torch in the dev container).
+_L_DEFAULT = [[1.0, 0.0, 0.0, 0.0],
+              [-0.3333333432674408, 0.9428090453147888, 0.0, 0.0],
+              [-0.3333333432674408, -0.471404492855072, 0.8164966106414795, 0.0],
+              [-0.3333333432674408, -0.471404492855072, -0.8164964914321899, 0.00042286395910196006]]
+
+
 def block_noise_cholesky(gamma=1 / 3):
+    if abs(gamma - 1 / 3) < 1e-12:
+        return torch.tensor(_L_DEFAULT, dtype=torch.float32)
     cov = torch.eye(4) * (1 + gamma) - torch.ones(4, 4) * gamma
-    # MultivariateNormal uses torch.linalg.cholesky(cov) as scale_tril
-    return torch.distributions.MultivariateNormal(torch.zeros(4), cov).scale_tril
+    return torch.linalg.cholesky(cov)
 
 
 def block_noise_from_normal(eps, bs, ch, t, h, w, gamma=1 / 3):

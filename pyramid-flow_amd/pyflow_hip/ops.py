@@ -10,6 +10,36 @@ from . import lib as L
 from .lib import GemmDesc, AttnDesc, ConvDesc, check, ptr, stream, GEMM_GATE_RES, GEMM_OUT_F32  # noqa: F401
 
 
+class KernelProfiler:
+    """HIP-event timing of individual launches on torch's current stream (the stream every pyflow kernel is
+    enqueued on).  bench.py enables it for a deterministic sample of DiT forwards; disabled = zero overhead."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}        # name -> list of (start_event, end_event, work)
+
+    def launch(self, name, work, fn):
+        if not self.enabled:
+            return fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.setdefault(name, []).append((e0, e1, work))
+
+    def summary(self):
+        """name -> dict(launches, ms_total, work_total) ; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[name] = dict(launches=len(recs), ms_total=ms, work_total=float(sum(w for _, _, w in recs)))
+        return out
+
+
+PROFILER = KernelProfiler()
+
+
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
          a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0):
@@ -26,7 +56,7 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr = M, N, K, lda, ldw, ldc, ldr
     d.strideA, d.strideC, d.strideR = strideA, strideC, strideR
     d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
-    check(lib.pf_gemm_bf16(C.byref(d), stream()))
+    PROFILER.launch("gemm", 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
 
 
 def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale):
@@ -44,7 +74,8 @@ def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt,
     d.a_lo, d.a_hi, d.b_hi = plan.a_lo.data_ptr(), plan.a_hi.data_ptr(), plan.b_hi.data_ptr()
     d.tile_kv_end = plan.tile_kv_end.data_ptr()
     d.scale = scale
-    check(lib.pf_attention_bf16(C.byref(d), stream()))
+    PROFILER.launch("attention", 4.0 * plan.useful_pairs() * 64 * H,
+                    lambda: check(lib.pf_attention_bf16(C.byref(d), stream())))
 
 
 def v_transpose(V, Vt, v_off, ldv, strideV, B, H, Lseq, Lp):

@@ -27,9 +27,18 @@ DEFAULT_NEGATIVE = ("cartoon style, worst quality, low quality, blurry, absolute
 
 
 def block_noise_cholesky(gamma):
-    cov = torch.eye(4, dtype=torch.float64) * (1 + gamma) - torch.ones(4, 4, dtype=torch.float64) * gamma
-    # rank-deficient by construction (1 + gamma - 4 gamma = 0 at gamma = 1/3): regularise like torch's fp32 path
-    return torch.linalg.cholesky(cov.float()).float()
+    """L with L L^T = (1+g) I - g 11^T (diagonal 1, off-diagonal -g: pipeline.py:699).  The matrix is singular at
+    g = 1/3 (the four values of a 2x2 block sum to
+    zero), so the factor is written in closed form instead of calling a (CPU-dependent) Cholesky on it."""
+    L = torch.zeros(4, 4, dtype=torch.float64)
+    a, b = 1.0, -gamma                  # diagonal / off-diagonal of the covariance
+    for j in range(4):
+        s = sum(L[j, k] ** 2 for k in range(j))
+        L[j, j] = math.sqrt(max(a - s, 0.0))
+        for i in range(j + 1, 4):
+            t = sum(L[i, k] * L[j, k] for k in range(j))
+            L[i, j] = (b - t) / L[j, j] if L[j, j] > 1e-12 else 0.0
+    return L.float()
 
 
 class PyramidDiTForVideoGeneration:

@@ -97,5 +97,7 @@ class SequencePlan:
 
     def useful_pairs(self):
         """number of unmasked (q, k) pairs summed over the batch (for FLOP accounting)."""
-        h = self.host
-        return int((h["a_hi"] - h["a_lo"]).sum() + (h["b_hi"] - self.Lt).sum())
+        if getattr(self, "_pairs", None) is None:
+            h = self.host
+            self._pairs = int((h["a_hi"] - h["a_lo"]).astype(np.int64).sum() + (h["b_hi"] - self.Lt).astype(np.int64).sum())
+        return self._pairs

@@ -110,7 +110,8 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None):
         assert (res.Hp, res.Wp, res.Cp) == (dst.Hp, dst.Wp, dst.Cp)
     d.out_scale = 1.0
     d.out_t_shift = t_shift
-    check(lib.pf_conv3d_bf16(C.byref(d), stream()))
+    ops.PROFILER.launch("conv3d", 2.0 * Tc * src.H * src.W * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
+                        lambda: check(lib.pf_conv3d_bf16(C.byref(d), stream())))
     if dst is not None:
         dst.cur = Tc * st + t_shift
 
