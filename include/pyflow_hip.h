@@ -48,6 +48,11 @@ typedef struct {
     int gate_stride, batch, gelu_from, flags;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
+/* Kernel selection for pf_gemm_bf16 / pf_conv3d_bf16 (tuning / test hook; results are identical up to fp32
+ * summation order).  0 = automatic (256 x BN ping-pong kernel for large problems whose N is a multiple of 192 or
+ * 256, the 128 x 128 kernel otherwise), -1 = always the 128 x 128 kernel, 128/192/256 = force the 256 x BN kernel
+ * whenever BN divides N.  Default 0, or the PF_GEMM256 environment variable. */
+int pf_gemm_set_policy(int force);
 
 /* ------------------------------------------------------------------ CausalConv3d ----------------
  * Implicit-GEMM convolution over a channels-last, zero-padded input (replaces CausalConv3d.forward,

@@ -13,8 +13,12 @@
 // of tile k+1 are issued right after the barrier that publishes tile k and fly under its MFMAs.
 // Epilogue: accumulators are staged through LDS as fp32, then every thread streams whole
 // 16-byte bf16 pieces (bias / GELU-tanh / gate*x+residual applied in fp32) -> coalesced stores.
+#include <stdlib.h>
 #include "common.h"
 #include "pyflow_hip.h"
+#include "gemm_args.h"
+
+using namespace pfgemm;
 
 namespace {
 
@@ -22,36 +26,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + W
 constexpr int SMEM_BYTES = 2 * BUF_BYTES;        // double buffered = 64 KiB (= fp32 128x128 epilogue stage)
-
-struct ConvGeom {            // implicit-GEMM addressing of a channels-last, spatially padded input
-    int H, W;                // output spatial size (rows of the GEMM are (t,h,w) pixels)
-    int Hp, Wp;              // padded input spatial pitch (H+2pad, W+2pad)
-    int Cin;                 // input channels (K = ntaps*Cin)
-    int kt, kh, kw;          // taps
-    long long base_off;      // element offset of tap (0,0,0) for output pixel (0,0,0)
-};
-
-struct OutMap {              // where output row m / column-group g lands
-    int mode;                // 0 = plain [M, ldc];  1 = pixel map into [To,Hop,Wop,C] with shuffles
-    int H, W;                // GEMM-row pixel grid
-    int st, sh, sw;          // upsample factors (depth-to-time, pixel shuffle)
-    int Cg;                  // channels per group (N = st*sh*sw*Cg for shuffles)
-    int Hop, Wop;            // padded output pitches
-    long long base_off;      // element offset of output pixel (0,0,0) channel 0
-    int Cout_pitch;          // channel pitch of the output buffer
-    int t_shift;             // added to the output frame index; negative frames are dropped
-};
-
-struct Args {
-    const bf16_t* A; const bf16_t* W; void* C;
-    const float* bias; const bf16_t* res; const float* gate;
-    int M, N, K, lda, ldw, ldc, ldr;
-    long long sA, sC, sR;    // batch strides (elements)
-    int gate_stride, batch;
-    int gelu_from, flags, n_valid;
-    float out_scale;
-    ConvGeom cg; OutMap om;
-};
 
 template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
@@ -231,11 +205,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
 
 int pf_set_err(const char* m);
 #define set_err pf_set_err
+int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force);
+int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, int variant, hipStream_t stream);
+
+// PF_GEMM256 = 0 (auto, default) | 128 | 192 | 256 (force that tile width when it divides N) | -1 (never)
+static int g_gemm256_force = -2;
+static int g_gemm256_variant = 1;      // 0: barrier per slot, 1: one barrier per K-tile
+static int gemm256_force() {
+    if (g_gemm256_force == -2) {
+        const char* e = getenv("PF_GEMM256");
+        g_gemm256_force = e ? atoi(e) : 0;
+    }
+    return g_gemm256_force;
+}
+extern "C" int pf_gemm_set_policy(int force) {
+    if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
+        return set_err("pf_gemm_set_policy: force must be 0, -1, 128, 192 or 256");
+    g_gemm256_force = force;
+    return 0;
+}
+extern "C" int pf_gemm_set_variant(int v) {     // tuning hook, not part of the documented ABI
+    g_gemm256_variant = v;
+    return 0;
+}
 
 extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
     if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
-    if (d->N % BN != 0) return set_err("pf_gemm_bf16: N must be a multiple of 128");
+    const int bn256 = pf_gemm256_pick((long long)d->M * d->batch, d->M, d->batch, d->N, gemm256_force());
+    if (!bn256 && d->N % BN != 0) return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (d->K % BK != 0 || d->K <= 0) return set_err("pf_gemm_bf16: K must be a positive multiple of 64");
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8)) return set_err("pf_gemm_bf16: leading dims must be multiples of 8");
     if ((d->flags & PF_GEMM_GATE_RES) && !d->res) return set_err("pf_gemm_bf16: GATE_RES needs res");
@@ -247,6 +245,12 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
     a.out_scale = 1.f; a.n_valid = d->N;
     if (a.gelu_from % 8) return set_err("pf_gemm_bf16: gelu_from must be a multiple of 8");
+    if (const int bn = bn256) {
+        pf_gemm256_launch(a, bn, false, g_gemm256_variant, stream);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
+        return 0;
+    }
     const int grid = (d->N / BN) * ((d->M + BM - 1) / BM) * d->batch;
     hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipLaunchKernelGGL(gemm_kernel<false>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
@@ -272,6 +276,12 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     a.cg = ConvGeom{d->H, d->W_, d->Hp, d->Wp, d->Cin, d->kt, d->kh, d->kw, d->in_base_off};
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
+    if (const int bn = pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force())) {
+        pf_gemm256_launch(a, bn, true, g_gemm256_variant, stream);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
+        return 0;
+    }
     const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
     hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     hipLaunchKernelGGL(gemm_kernel<true>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);

@@ -1,0 +1,38 @@
+// Kernel-argument structures shared by the two GEMM kernels (gemm.hip: 128x128 tile, gemm256.hip: 256xBN ping-pong).
+#pragma once
+#include "common.h"
+
+namespace pfgemm {
+
+struct ConvGeom {            // implicit-GEMM addressing of a channels-last, spatially padded input
+    int H, W;                // output spatial size (rows of the GEMM are (t,h,w) pixels)
+    int Hp, Wp;              // padded input spatial pitch (H+2pad, W+2pad)
+    int Cin;                 // input channels (K = ntaps*Cin)
+    int kt, kh, kw;          // taps
+    long long base_off;      // element offset of tap (0,0,0) for output pixel (0,0,0)
+};
+
+struct OutMap {              // where output row m / column-group g lands
+    int mode;                // 0 = plain [M, ldc];  1 = pixel map into [To,Hop,Wop,C] with shuffles
+    int H, W;                // GEMM-row pixel grid
+    int st, sh, sw;          // upsample factors (depth-to-time, pixel shuffle)
+    int Cg;                  // channels per group (N = st*sh*sw*Cg for shuffles)
+    int Hop, Wop;            // padded output pitches
+    long long base_off;      // element offset of output pixel (0,0,0) channel 0
+    int Cout_pitch;          // channel pitch of the output buffer
+    int t_shift;             // added to the output frame index; negative frames are dropped
+};
+
+struct Args {
+    const bf16_t* A; const bf16_t* W; void* C;
+    const float* bias; const bf16_t* res; const float* gate;
+    int M, N, K, lda, ldw, ldc, ldr;
+    long long sA, sC, sR;    // batch strides (elements)
+    int gate_stride, batch;
+    int gelu_from, flags, n_valid;
+    float out_scale;
+    ConvGeom cg; OutMap om;
+};
+
+
+}  // namespace pfgemm

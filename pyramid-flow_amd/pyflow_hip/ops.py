@@ -59,6 +59,11 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     PROFILER.launch("gemm", 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
 
 
+def gemm_set_policy(force):
+    """0 auto | -1 128x128 kernel only | 128/192/256 force the 256xBN kernel (pf_gemm_set_policy)."""
+    check(L.load().pf_gemm_set_policy(C.c_int(force)))
+
+
 def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale):
     lib = L.load()
     d = AttnDesc()

@@ -6,4 +6,4 @@ export TMPDIR=/tmp
 ( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5 ) > gpurun_out/smoke.log
 ( time timeout 600 python bench.py --workload c2_384p_121f --no-cpu-baseline 2>&1 | tail -5 ) > gpurun_out/bench_c2.log 2>&1
 ( time timeout 1200 python bench.py --no-cpu-baseline 2>&1 | tail -5 ) > gpurun_out/bench_c3.log 2>&1
-tail -3 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench_c2.log gpurun_out/bench_c3.log
+for f in pytest_gpu smoke bench_c2 bench_c3; do tail -n 3 gpurun_out/$f.log; done

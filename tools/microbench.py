@@ -11,7 +11,7 @@ from pyflow_hip import ops  # noqa: E402
 from pyflow_hip.plan import SequencePlan  # noqa: E402
 
 
-def timeit(fn, iters=5, warm=2):
+def timeit(fn, iters=20, warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -25,15 +25,36 @@ def timeit(fn, iters=5, warm=2):
 
 
 def bench_gemm():
+    # clock ramp: ~0.3 s of GEMM work before anything is timed
+    Aw = torch.randn(8192, 4096, device="cuda").to(torch.bfloat16)
+    Ww = torch.randn(4096, 4096, device="cuda").to(torch.bfloat16)
+    Cw = torch.empty(8192, 4096, device="cuda", dtype=torch.bfloat16)
+    for _ in range(300):
+        ops.gemm(Aw, Ww, Cw, 8192, 4096, 4096, 4096, 4096, 4096)
+    torch.cuda.synchronize()
     d = 1920
     M = 2 * 15488
-    for (N, K, gelu) in [(d, d, -1), (3 * d, d, -1), (4 * d, d, 0), (d, 4 * d, -1), (7 * d, d, 3 * d), (d, 5 * d, -1)]:
-        A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    shapes = [(M, d, d, -1), (M, 3 * d, d, -1), (M, 4 * d, d, 0), (M, d, 4 * d, -1), (M, 7 * d, d, 3 * d), (M, d, 5 * d, -1),
+              (2 * 3968, 7 * d, d, 3 * d), (2 * 1088, 7 * d, d, 3 * d),
+              # VAE conv-like GEMM shapes (plain GEMM addressing): 8 frames x 256 x 256 px, Cin*27 x Cout
+              (8 * 256 * 256, 128, 27 * 128, -1), (8 * 128 * 128, 256, 27 * 256, -1), (4 * 64 * 64, 2048, 27 * 512, -1)]
+    for (Mx, N, K, gelu) in shapes:
+        A = torch.randn(Mx, K, device="cuda").to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
-        C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        C = torch.empty(Mx, N, device="cuda", dtype=torch.bfloat16)
         bias = torch.zeros(N, device="cuda")
-        ms = timeit(lambda: ops.gemm(A, W, C, M, N, K, K, K, N, bias=bias, gelu_from=gelu))
-        print(f"gemm M={M} N={N} K={K} gelu_from={gelu}: {ms:.3f} ms  {2 * M * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
+        line = f"gemm M={Mx} N={N} K={K} gelu_from={gelu}:"
+        lib = ops.L.load()
+        for pol, var in ((-1, 0), (128, 1), (192, 0), (192, 1), (256, 0), (256, 1)):
+            if pol > 0 and N % pol:
+                continue
+            ops.gemm_set_policy(pol)
+            lib.pf_gemm_set_variant(var)
+            ms = min(timeit(lambda: ops.gemm(A, W, C, Mx, N, K, K, K, N, bias=bias, gelu_from=gelu)) for _ in range(2))
+            line += f"  [{'128x128' if pol < 0 else '256x%d/v%d' % (pol, var)}] {ms:.3f} ms {2 * Mx * N * K / ms / 1e9:.0f} TF"
+        ops.gemm_set_policy(0)
+        lib.pf_gemm_set_variant(1)
+        print(line, flush=True)
 
 
 def bench_attn():
