@@ -24,6 +24,7 @@ constexpr int QB = 128, KB = 64, HD = 64;
 constexpr int KTILE = KB * HD * 2;     // 8 KiB
 constexpr int ABUF = 2 * KTILE;        // K + V^T
 constexpr float NEG = -1.0e30f;
+constexpr float DEFER = 6.0f;        // log2 units: P stays below 2^6 between rescales
 
 struct AArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m = NEG, l = 0.f;
+    const int wmax_s = __builtin_amdgcn_readfirstlane(wmax), wmin_s = __builtin_amdgcn_readfirstlane(wmin);
+    const float NINF = -__builtin_inff();
 
     if (ntiles > 0) issue(0, 0);
     for (int jt = 0; jt < ntiles; ++jt) {
@@ -109,32 +112,44 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
         if (jt + 1 < ntiles) issue(jt + 1, buf ^ 1);
         const int j0 = jt * KB;
         const bool has_text = j0 < p.Lt;
-        if (!has_text && j0 >= wmax) continue;     // wave-uniform: nothing visible for these 32 rows
+        if (!has_text && j0 >= wmax_s) continue;     // scalar: nothing visible for these 32 rows
         const char* sk = smem + buf * ABUF;
         const char* sv = sk + KTILE;
+        // ---- all K fragments first, then the S^T MFMAs (the compiler counts lgkmcnt down as they arrive)
+        bf16x8_t kf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ((2 * ks + hi) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) kf[i][ks] = *(const bf16x8_t*)(sk + (i * 32 + frow) * 128 + ch);
+        }
         f32x16_t s[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int ch = ((2 * ks + hi) ^ swz) << 4;
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sk + (i * 32 + frow) * 128 + ch);
-                s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[i], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- V^T fragments are requested now and land under the softmax arithmetic
+        bf16x8_t vf[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = ((2 * g + hi) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vf[i][g] = *(const bf16x8_t*)(sv + (i * 32 + frow) * 128 + ch);
         }
-        const bool masked = has_text || (j0 + KB > wmin);
-        if (masked) {
+        if (has_text || (j0 + KB > wmin_s)) {        // scalar: tile straddles a visibility boundary of some row
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = j0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const bool ok = key < p.Lt ? (key >= alo && key < ahi) : (key < bhi);
-                    s[i][r] = ok ? s[i][r] : NEG;
+                    s[i][r] = ok ? s[i][r] : NINF;      // exp2(-inf) == 0: no select needed after the exponential
                 }
         }
         float mt = s[0][0];
@@ -142,40 +157,43 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[i][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float mn = fmaxf(m, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
-        const float msc = mn * p.sc;
-        m = mn;
+        {   // the row's other 32 keys live in lane ^ 32
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+            mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        // ---- deferred rescale: keep the running max while no row of the wave grew by more than 2^DEFER
+        if (__builtin_amdgcn_ballot_w64((mt - m) * p.sc > DEFER) != 0) {
+            const float mn = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float msc = m * p.sc;
         float ps = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][r], p.sc, -msc));
-                if (masked) e = (s[i][r] == NEG) ? 0.f : e;
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][r], p.sc, -msc));
                 s[i][r] = e;
                 ps += e;
             }
-        l = l * alpha + ps;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l += ps;
         bf16x8_t pf[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[g][e] = (bf16_t)s[g >> 1][8 * (g & 1) + e];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch = ((2 * g + hi) ^ swz) << 4;
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bf16x8_t vf = *(const bf16x8_t*)(sv + (i * 32 + frow) * 128 + ch);
-                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g], o[i], 0, 0, 0);
-            }
-        }
+            for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][g], pf[g], o[i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     }
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
