@@ -95,6 +95,8 @@ typedef struct {
     const int* a_lo; const int* a_hi; const int* b_hi; /* [B][L] */
     const int* tile_kv_end;                            /* [B][ceil(L/128)] */
     float scale;
+    int q_prescaled;   /* 1: Q was already multiplied by scale*log2(e) (pf_qk_norm_rope q_scale): `scale` is ignored and
+                          the scores are used as base-2 exponents directly (saves one FMA per score) */
 } pf_attn_desc;
 int pf_attention_bf16(const pf_attn_desc* d, pf_stream_t stream);
 int pf_v_transpose(const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b, long long strideVt_h,
@@ -111,10 +113,11 @@ int pf_ln_modulate(const void* x, void* y, const float* shift, const float* scal
 /* pf_qk_norm_rope: in place on a fused projection buffer [B][L][ld]: q at column q_off, k at k_off
  *   (H heads x 64).  RMSNorm(eps) with fp32 weights (text rows < Lt use *_txt, NULL = same as image:
  *   norm_added_q/k vs norm_q/k, flux_block.py:846-850, 772-775), then RoPE with the per-token table
- *   rope[L][32][cos,sin] (flux_block.py:34-39). */
+ *   rope[L][32][cos,sin] (flux_block.py:34-39).  q (not k) is multiplied by q_scale in fp32 before its single
+ *   rounding to bf16 (1.0 = reference values; softmax_scale*log2(e) feeds pf_attention_bf16's q_prescaled path). */
 int pf_qk_norm_rope(void* qkv, int ld, long long bstride, int q_off, int k_off, const float* wq_img,
                     const float* wk_img, const float* wq_txt, const float* wk_txt, const float* rope, int B, int L,
-                    int Lt, int H, float eps, pf_stream_t stream);
+                    int Lt, int H, float eps, float q_scale, pf_stream_t stream);
 /* pf_gemv_f32: y[b][0:N] (+)= W[N][K](bf16) . act(x[b][0:K]) + bias, 1 <= B <= 4, act = SiLU if silu_in
  *   (time_text_embed and every AdaLN linear: modeling_embedding.py:185-200, modeling_normalization.py:160,227,111) */
 int pf_gemv_f32(const void* W, int ldw, const float* bias, const float* x, int ldx, float* y, int ldy, int N, int K,

@@ -36,7 +36,8 @@ struct AArgs {
     float sc;   // softmax scale * log2(e)
 };
 
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
+template <bool PRE>
+__global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,7 +101,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m = NEG, l = 0.f;
+    float m = PRE ? 0.f : NEG, l = 0.f;
+    bool fresh = true;                 // PRE: the row has not seen a key yet (its reference max is still unset)
+    f32x16_t negm;                     // PRE: -m broadcast, the C operand of the first S^T MFMA (scores come out as s - m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
     const int wmax_s = __builtin_amdgcn_readfirstlane(wmax), wmin_s = __builtin_amdgcn_readfirstlane(wmin);
     const float NINF = -__builtin_inff();
 
@@ -124,13 +129,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
             for (int i = 0; i < 2; ++i) kf[i][ks] = *(const bf16x8_t*)(sk + (i * 32 + frow) * 128 + ch);
         }
         f32x16_t s[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
         __builtin_amdgcn_s_setprio(1);
+        if (PRE) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][0], qf[0], negm, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
+                s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][0], qf[0], s[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -161,27 +173,54 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AArgs p) {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
             mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        // ---- deferred rescale: keep the running max while no row of the wave grew by more than 2^DEFER
-        if (__builtin_amdgcn_ballot_w64((mt - m) * p.sc > DEFER) != 0) {
-            const float mn = fmaxf(m, mt);
-            const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
-            m = mn;
-            l *= alpha;
+        float ps = 0.f;
+        if (PRE) {
+            // q was pre-multiplied by scale*log2(e) (pf_qk_norm_rope q_scale) and s already holds score - m:
+            // the common path is exp2 / add / convert only.
+            const bool seen = mt > NINF;
+            if (__builtin_amdgcn_ballot_w64(mt > DEFER || (fresh && seen)) != 0) {
+                const float delta = fresh ? (seen ? mt : 0.f) : fmaxf(mt, 0.f);
+                const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                fresh = fresh && !seen;
+                m += delta;
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; s[i][r] -= delta; }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        const float msc = m * p.sc;
-        float ps = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[i][r]);
+                    s[i][r] = e;
+                    ps += e;
+                }
+        } else {
+            // ---- deferred rescale: keep the running max while no row of the wave grew by more than 2^DEFER
+            if (__builtin_amdgcn_ballot_w64((mt - m) * p.sc > DEFER) != 0) {
+                const float mn = fmaxf(m, mt);
+                const float alpha = __builtin_amdgcn_exp2f((m - mn) * p.sc);
+                m = mn;
+                l *= alpha;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][r], p.sc, -msc));
-                s[i][r] = e;
-                ps += e;
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             }
+            const float msc = m * p.sc;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][r], p.sc, -msc));
+                    s[i][r] = e;
+                    ps += e;
+                }
+        }
         l += ps;
         bf16x8_t pf[4];
 #pragma unroll
@@ -280,7 +319,8 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.a_lo = d->a_lo; a.a_hi = d->a_hi; a.b_hi = d->b_hi; a.tile_kv_end = d->tile_kv_end;
     a.sc = d->scale * 1.4426950408889634f;
     const int grid = a.nqt * a.H * a.B;
-    hipLaunchKernelGGL(attn_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (d->q_prescaled) hipLaunchKernelGGL(attn_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));
     return 0;

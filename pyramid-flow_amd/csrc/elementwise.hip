@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* x, bf16_t* y,
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, long long bstride, int q_off, int k_off,
                                                            const float* wq_img, const float* wk_img,
                                                            const float* wq_txt, const float* wk_txt,
-                                                           const float* rope, int L, int Lt, int H, int B, float eps) {
+                                                           const float* rope, int L, int Lt, int H, int B, float eps, float q_scale) {
     const long long unit = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;   // over B*L*H*2
     const int sub = threadIdx.x & 7;
     const long long total = (long long)B * L * H * 2;
@@ -103,14 +103,15 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, 
     const float r = rsqrtf(ss * (1.f / 64.f) + eps);
     const float* w = (tok < Lt) ? (which ? wk_txt : wq_txt) : (which ? wk_img : wq_img);
     const float* cs = rope + ((long long)tok * 32 + sub * 4) * 2;   // [L][32][cos,sin]
+    const float osc = which ? 1.f : q_scale;
     float o[8];
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
         const float x0 = v[2 * pr] * r * w[sub * 8 + 2 * pr];
         const float x1 = v[2 * pr + 1] * r * w[sub * 8 + 2 * pr + 1];
         const float c = cs[2 * pr], s = cs[2 * pr + 1];
-        o[2 * pr] = c * x0 - s * x1;
-        o[2 * pr + 1] = s * x0 + c * x1;
+        o[2 * pr] = (c * x0 - s * x1) * osc;
+        o[2 * pr + 1] = (s * x0 + c * x1) * osc;
     }
     *(u32x4_t*)ptr = pack8(o);
 }
@@ -289,13 +290,13 @@ extern "C" int pf_ln_modulate(const void* x, void* y, const float* shift, const 
 
 extern "C" int pf_qk_norm_rope(void* qkv, int ld, long long bstride, int q_off, int k_off, const float* wq_img,
                                const float* wk_img, const float* wq_txt, const float* wk_txt, const float* rope,
-                               int B, int L, int Lt, int H, float eps, hipStream_t stream) {
+                               int B, int L, int Lt, int H, float eps, float q_scale, hipStream_t stream) {
     if (!qkv || !wq_img || !wk_img || !rope) return pf_set_err("pf_qk_norm_rope: null operand");
     if (ld % 8 || q_off % 8 || k_off % 8) return pf_set_err("pf_qk_norm_rope: misaligned layout");
     const long long threads = (long long)B * L * H * 2 * 8;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
                        (bf16_t*)qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt ? wq_txt : wq_img,
-                       wk_txt ? wk_txt : wk_img, rope, L, Lt, H, B, eps);
+                       wk_txt ? wk_txt : wk_img, rope, L, Lt, H, B, eps, q_scale);
     CHECK_LAUNCH();
     return 0;
 }

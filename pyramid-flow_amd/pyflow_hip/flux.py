@@ -196,6 +196,7 @@ class FluxEngine:
         Ld, L3, L4, L7 = L * d, L * 3 * d, L * 4 * d, L * 7 * d
         mlp_base = B * L3          # mlp region of `big` for the double blocks
         scale = 64 ** -0.5
+        qs = scale * ops.LOG2E     # folded into q by qk_norm_rope; attention then works in base-2 exponents
 
         # ---- embed: text rows <- cached context, image rows <- x_embedder(patchify) ----
         ops.copy_rows(ctx, hidden, Lt, d, d, d, Lt * d, Ld, B)
@@ -225,9 +226,9 @@ class FluxEngine:
             ops.gemm(xn, blk["kvq_txt"][0], big, Lt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
                      strideA=Ld, strideC=L3)
             ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
-                             blk["norm_added_k"], plan.rope, B, L, Lt, H)
+                             blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs)
             ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
-            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale)
+            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
             ops.gemm(big, blk["o_img"][0], hidden, L_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=Lt * 3 * d + 2 * d, c_off=Lt * d, r_off=Lt * d)
@@ -254,9 +255,9 @@ class FluxEngine:
             ln(L, 0, mb, mb + d)
             ops.gemm(xn, blk["kvqm"][0], big, L, 7 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
                      strideC=L7, gelu_from=3 * d)
-            ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H)
+            ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H, q_scale=qs)
             ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
-            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale)
+            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
             ops.gemm(big, blk["out"][0], hidden, L, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=2 * d)

@@ -64,7 +64,10 @@ def gemm_set_policy(force):
     check(L.load().pf_gemm_set_policy(C.c_int(force)))
 
 
-def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale):
+LOG2E = 1.4426950408889634
+
+
+def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale, q_prescaled=False):
     lib = L.load()
     d = AttnDesc()
     d.Q = Q.data_ptr() + 2 * q_off
@@ -79,6 +82,7 @@ def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt,
     d.a_lo, d.a_hi, d.b_hi = plan.a_lo.data_ptr(), plan.a_hi.data_ptr(), plan.b_hi.data_ptr()
     d.tile_kv_end = plan.tile_kv_end.data_ptr()
     d.scale = scale
+    d.q_prescaled = int(q_prescaled)
     PROFILER.launch("attention", 4.0 * plan.useful_pairs() * 64 * H,
                     lambda: check(lib.pf_attention_bf16(C.byref(d), stream())))
 
@@ -102,11 +106,12 @@ def ln_modulate(x, y, shift, scale, D, B, rows, x_bstride, y_bstride, ldx, ldy, 
                              C.c_float(eps), stream()))
 
 
-def qk_norm_rope(qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt, wk_txt, rope, B, Lseq, Lt, H, eps=1e-6):
+def qk_norm_rope(qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt, wk_txt, rope, B, Lseq, Lt, H, eps=1e-6,
+                 q_scale=1.0):
     lib = L.load()
     check(lib.pf_qk_norm_rope(ptr(qkv), C.c_int(ld), C.c_longlong(bstride), C.c_int(q_off), C.c_int(k_off),
                               ptr(wq_img), ptr(wk_img), ptr(wq_txt), ptr(wk_txt), ptr(rope), C.c_int(B),
-                              C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), stream()))
+                              C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), C.c_float(q_scale), stream()))
 
 
 def gemv(W, bias, x, y, N, K, B, ldw=None, ldx=None, ldy=None, silu_in=False, accumulate=False, y_off=0):

@@ -140,6 +140,10 @@ def test_qk_norm_rope_and_vtranspose():
     assert rel_l2(qkv[..., 2 * d:].float(), ref(q0[..., 2 * d:], ws[0], ws[2])) < 4e-3
     assert rel_l2(qkv[..., :d].float(), ref(q0[..., :d], ws[1], ws[3])) < 4e-3
     assert torch.equal(qkv[..., d:2 * d], q0[..., d:2 * d])
+    q2 = q0.clone()
+    ops.qk_norm_rope(q2, 3 * d, L * 3 * d, 2 * d, 0, ws[0], ws[1], ws[2], ws[3], plan.rope, B, L, Lt, H, q_scale=0.18)
+    assert rel_l2(q2[..., 2 * d:].float(), 0.18 * ref(q0[..., 2 * d:], ws[0], ws[2])) < 4e-3
+    assert torch.equal(q2[..., :2 * d], qkv[..., :2 * d])          # k and v untouched by q_scale
     Lp = plan.Lp
     vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device=DEV)
     ops.v_transpose(qkv, vT, d, 3 * d, L * 3 * d, B, H, L, Lp)
@@ -157,7 +161,8 @@ def test_qk_norm_rope_and_vtranspose():
     ([(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)], 16, (5, 12)),
     ([(3, 8, 16), (1, 16, 32), (1, 32, 48), (1, 32, 48)], 128, (40, 96)),
 ])
-def test_attention_masked(clips, Lt, valid):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_masked(clips, Lt, valid, prescaled):
     from pyflow_hip import ops
     from pyflow_hip.plan import SequencePlan
     B, H = 2, 3
@@ -174,10 +179,17 @@ def test_attention_masked(clips, Lt, valid):
     k = qkv[..., :d].float().view(B, L, H, 64).transpose(1, 2)
     v = qkv[..., d:2 * d].float().view(B, L, H, 64).transpose(1, 2)
     dm = torch.from_numpy(plan.dense_mask()).to(DEV)[:, None]
-    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=dm).transpose(1, 2).reshape(B, L, d)
+    if prescaled:
+        # q already carries scale*log2(e) (as pf_qk_norm_rope(q_scale=...) leaves it): softmax base 2 of q.k
+        qkv[..., 2 * d:] = (qkv[..., 2 * d:].float() * (0.125 * ops.LOG2E)).to(torch.bfloat16)
+        q = qkv[..., 2 * d:].float().view(B, L, H, 64).transpose(1, 2)
+        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=dm, scale=math.log(2.0)).transpose(1, 2).reshape(B, L, d)
+    else:
+        ref = F.scaled_dot_product_attention(q, k, v, attn_mask=dm).transpose(1, 2).reshape(B, L, d)
     vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device=DEV)
     ops.v_transpose(qkv, vT, d, 3 * d, L * 3 * d, B, H, L, Lp)
-    ops.attention(qkv, qkv, vT, qkv, 2 * d, 0, 2 * d, 3 * d, L * 3 * d, B, H, L, Lp, Lt, plan, 0.125)
+    ops.attention(qkv, qkv, vT, qkv, 2 * d, 0, 2 * d, 3 * d, L * 3 * d, B, H, L, Lp, Lt, plan, 0.125,
+                  q_prescaled=prescaled)
     out = qkv[..., 2 * d:].float()
     assert torch.isfinite(out).all()
     assert rel_l2(out, ref) < 1e-2

@@ -67,14 +67,19 @@ def bench_attn():
         mask[1, :96] = 1
         plan = SequencePlan(clips, mask, [16, 24, 24], "cuda")
         L, Lp = plan.L, plan.Lp
-        qkv = torch.randn(B, L, 3 * d, device="cuda").to(torch.bfloat16)
+        qkv = torch.randn(B, L, 3 * d, device="cuda")
+        qkv[..., 2 * d:] *= 0.5       # q ~ scores of a few units in the exponent, like normalised q.k/8
+        qkv = qkv.to(torch.bfloat16)
         vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device="cuda")
         ops.v_transpose(qkv, vT, d, 3 * d, L * 3 * d, B, H, L, Lp)
         out = torch.empty_like(qkv)
-        ms = timeit(lambda: ops.attention(qkv, qkv, vT, out, 2 * d, 0, 2 * d, 3 * d, L * 3 * d, B, H, L, Lp, Lt, plan, 0.125))
         useful = 4 * plan.useful_pairs() * 64 * H
         dense = 4 * B * L * L * 64 * H
-        print(f"attn {name} L={L}: {ms:.3f} ms  useful {useful / ms / 1e9:.1f} TFLOP/s (dense-equivalent {dense / ms / 1e9:.1f})", flush=True)
+        for pre in (False, True):
+            ms = min(timeit(lambda: ops.attention(qkv, qkv, vT, out, 2 * d, 0, 2 * d, 3 * d, L * 3 * d, B, H, L, Lp, Lt, plan,
+                                                  0.125, q_prescaled=pre)) for _ in range(2))
+            print(f"attn {name} L={L} prescaled={pre}: {ms:.3f} ms  useful {useful / ms / 1e9:.1f} TFLOP/s "
+                  f"(dense-equivalent {dense / ms / 1e9:.1f})", flush=True)
         ms = timeit(lambda: ops.v_transpose(qkv, vT, d, 3 * d, L * 3 * d, B, H, L, Lp))
         print(f"v_transpose L={L}: {ms:.3f} ms  {2 * B * L * d * 2 / ms / 1e6:.1f} GB/s", flush=True)
 
