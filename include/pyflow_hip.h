@@ -95,12 +95,14 @@ typedef struct {
     const int* a_lo; const int* a_hi; const int* b_hi; /* [B][L] */
     const int* tile_kv_end;                            /* [B][ceil(L/128)] */
     float scale;
+    int head_stride_qk; /* elements between consecutive heads inside a Q / K row (0 or 64 = packed heads; 192 in the
+                          head-major [k|v|q] layout of the sequence-parallel exchange buffers) */
     int q_prescaled;   /* 1: Q was already multiplied by scale*log2(e) (pf_qk_norm_rope q_scale): `scale` is ignored and
                           the scores are used as base-2 exponents directly (saves one FMA per score) */
 } pf_attn_desc;
 int pf_attention_bf16(const pf_attn_desc* d, pf_stream_t stream);
 int pf_v_transpose(const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b, long long strideVt_h,
-                   int B, int H, int L, int Lp, pf_stream_t stream);
+                   int B, int H, int L, int Lp, int head_stride /* 0 = 64 */, pf_stream_t stream);
 
 /* ------------------------------------------------------------------ token-wise ops ---------------
  * pf_ln_modulate: y = LN(x; no affine, eps) * (1 + scale[b]) + shift[b]   (AdaLayerNormZero/Single/
@@ -117,7 +119,7 @@ int pf_ln_modulate(const void* x, void* y, const float* shift, const float* scal
  *   rounding to bf16 (1.0 = reference values; softmax_scale*log2(e) feeds pf_attention_bf16's q_prescaled path). */
 int pf_qk_norm_rope(void* qkv, int ld, long long bstride, int q_off, int k_off, const float* wq_img,
                     const float* wk_img, const float* wq_txt, const float* wk_txt, const float* rope, int B, int L,
-                    int Lt, int H, float eps, float q_scale, pf_stream_t stream);
+                    int Lt, int H, float eps, float q_scale, int head_stride /* 0 = 64 */, pf_stream_t stream);
 /* pf_gemv_f32: y[b][0:N] (+)= W[N][K](bf16) . act(x[b][0:K]) + bias, 1 <= B <= 4, act = SiLU if silu_in
  *   (time_text_embed and every AdaLN linear: modeling_embedding.py:185-200, modeling_normalization.py:160,227,111) */
 int pf_gemv_f32(const void* W, int ldw, const float* bias, const float* x, int ldx, float* y, int ldy, int N, int K,

@@ -31,6 +31,7 @@ struct AArgs {
     int ldq, ldk, ldo;
     long long sQ, sK, sO, sVb, sVh;
     int Lp, L, H, B, Lt, nqt;
+    int hs_qk;             // elements between consecutive heads in Q and K (64 = packed heads)
     const int* a_lo; const int* a_hi; const int* b_hi;
     const int* tile_kv_end;
     float sc;   // softmax scale * log2(e)
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
     const int qrow = q0 + wid * 32 + frow;
     const bool qvalid = qrow < p.L;
     const int qr = qvalid ? qrow : p.L - 1;
-    const bf16_t* qp = p.Q + (long long)b * p.sQ + (long long)qr * p.ldq + h * HD + hi * 8;
+    const bf16_t* qp = p.Q + (long long)b * p.sQ + (long long)qr * p.ldq + h * p.hs_qk + hi * 8;
     bf16x8_t qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + ks * 16);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
     const int ntiles = (kv_end + KB - 1) / KB;
 
     // ---- DMA sources: wave owns pieces i = wid*2 + j (rows 8i..8i+7) of the K and V^T tiles ----
-    const bf16_t* kbase = p.K + (long long)b * p.sK + h * HD;
+    const bf16_t* kbase = p.K + (long long)b * p.sK + h * p.hs_qk;
     const bf16_t* vbase = p.Vt + (long long)b * p.sVb + (long long)h * p.sVh;
     int prow[2], pc[2];
 #pragma unroll
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
 // V [B, L, H*64] (row stride ldv) -> V^T [B, H, 64, Lp] with keys permuted inside each group of
 // 16 (bits 2 and 3 of the key index swapped) so the PV A-operand is one ds_read_b128 per lane.
 __global__ __launch_bounds__(256) void vtrans_kernel(const bf16_t* V, bf16_t* Vt, int ldv, long long sV,
-                                                     long long sVb, long long sVh, int L, int Lp, int H) {
+                                                     long long sVb, long long sVh, int L, int Lp, int H, int hs) {
     __shared__ unsigned short tile[64][66];
     const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(256) void vtrans_kernel(const bf16_t* V, bf16_t* Vt
         const int kk = j0 + key;
         unsigned short vals[16];
         if (kk < L) {
-            const u32x4_t a = *(const u32x4_t*)(V + (long long)b * sV + (long long)kk * ldv + h * 64 + dq);
-            const u32x4_t c = *(const u32x4_t*)(V + (long long)b * sV + (long long)kk * ldv + h * 64 + dq + 8);
+            const u32x4_t a = *(const u32x4_t*)(V + (long long)b * sV + (long long)kk * ldv + h * hs + dq);
+            const u32x4_t c = *(const u32x4_t*)(V + (long long)b * sV + (long long)kk * ldv + h * hs + dq + 8);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 vals[2 * e] = a[e] & 0xffff; vals[2 * e + 1] = a[e] >> 16;
@@ -318,6 +319,8 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.nqt = (d->L + QB - 1) / QB;
     a.a_lo = d->a_lo; a.a_hi = d->a_hi; a.b_hi = d->b_hi; a.tile_kv_end = d->tile_kv_end;
     a.sc = d->scale * 1.4426950408889634f;
+    a.hs_qk = d->head_stride_qk > 0 ? d->head_stride_qk : HD;
+    if (a.hs_qk % 8) return pf_set_err("pf_attention_bf16: head_stride_qk must be a multiple of 8");
     const int grid = a.nqt * a.H * a.B;
     if (d->q_prescaled) hipLaunchKernelGGL(attn_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
@@ -327,11 +330,12 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
 }
 
 extern "C" int pf_v_transpose(const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b,
-                              long long strideVt_h, int B, int H, int L, int Lp, hipStream_t stream) {
+                              long long strideVt_h, int B, int H, int L, int Lp, int head_stride, hipStream_t stream) {
     if (!V || !Vt) return pf_set_err("pf_v_transpose: null operand");
-    if (Lp % 64 || Lp < L || (ldv % 8)) return pf_set_err("pf_v_transpose: bad Lp/ldv");
+    if (head_stride <= 0) head_stride = 64;
+    if (Lp % 64 || Lp < L || (ldv % 8) || (head_stride % 8)) return pf_set_err("pf_v_transpose: bad Lp/ldv/head_stride");
     hipLaunchKernelGGL(vtrans_kernel, dim3(Lp / 64, H, B), dim3(256), 0, stream, (const bf16_t*)V, (bf16_t*)Vt,
-                       ldv, strideV, strideVt_b, strideVt_h, L, Lp, H);
+                       ldv, strideV, strideVt_b, strideVt_h, L, Lp, H, head_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));
     return 0;

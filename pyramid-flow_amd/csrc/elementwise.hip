@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* x, bf16_t* y,
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, long long bstride, int q_off, int k_off,
                                                            const float* wq_img, const float* wk_img,
                                                            const float* wq_txt, const float* wk_txt,
-                                                           const float* rope, int L, int Lt, int H, int B, float eps, float q_scale) {
+                                                           const float* rope, int L, int Lt, int H, int B, float eps, float q_scale, int hstride) {
     const long long unit = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;   // over B*L*H*2
     const int sub = threadIdx.x & 7;
     const long long total = (long long)B * L * H * 2;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, 
     const long long tokb = u2 / H;
     const int tok = tokb % L;
     const int b = tokb / L;
-    bf16_t* ptr = qkv + (long long)b * bstride + (long long)tok * ld + (which ? k_off : q_off) + h * 64 + sub * 8;
+    bf16_t* ptr = qkv + (long long)b * bstride + (long long)tok * ld + (which ? k_off : q_off) + h * hstride + sub * 8;
     float v[8];
     unpack8(*(const u32x4_t*)ptr, v);
     float ss = 0.f;
@@ -290,13 +290,15 @@ extern "C" int pf_ln_modulate(const void* x, void* y, const float* shift, const 
 
 extern "C" int pf_qk_norm_rope(void* qkv, int ld, long long bstride, int q_off, int k_off, const float* wq_img,
                                const float* wk_img, const float* wq_txt, const float* wk_txt, const float* rope,
-                               int B, int L, int Lt, int H, float eps, float q_scale, hipStream_t stream) {
+                               int B, int L, int Lt, int H, float eps, float q_scale, int head_stride,
+                               hipStream_t stream) {
     if (!qkv || !wq_img || !wk_img || !rope) return pf_set_err("pf_qk_norm_rope: null operand");
-    if (ld % 8 || q_off % 8 || k_off % 8) return pf_set_err("pf_qk_norm_rope: misaligned layout");
+    if (head_stride <= 0) head_stride = 64;
+    if (ld % 8 || q_off % 8 || k_off % 8 || head_stride % 8) return pf_set_err("pf_qk_norm_rope: misaligned layout");
     const long long threads = (long long)B * L * H * 2 * 8;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
                        (bf16_t*)qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt ? wq_txt : wq_img,
-                       wk_txt ? wk_txt : wk_img, rope, L, Lt, H, B, eps, q_scale);
+                       wk_txt ? wk_txt : wk_img, rope, L, Lt, H, B, eps, q_scale, head_stride);
     CHECK_LAUNCH();
     return 0;
 }

@@ -32,7 +32,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, double* 
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (pl < lanes) {
         const bf16_t* xf = x + base_off + (long long)f * frame_stride;
-        for (int p = p0 + pl; p < p1; p += lanes) {
+        int p = p0 + pl;
+        // four independent 16-byte loads in flight per thread
+        for (; p + 3 * lanes < p1; p += 4 * lanes) {
+            u32x4_t raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pp = p + u * lanes;
+                const int h = pp / W, w = pp - h * W;
+                raw[u] = *(const u32x4_t*)(xf + ((long long)h * Wp + w) * Cp + chunk * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(raw[u], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+            }
+        }
+        for (; p < p1; p += lanes) {
             const int h = p / W, w = p - h * W;
             float v[8];
             unpack8(*(const u32x4_t*)(xf + ((long long)h * Wp + w) * Cp + chunk * 8), v);
@@ -90,7 +108,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* 
     const int p1 = min(p0 + pix_per_block, H * W);
     const bf16_t* xf = x + off_in + (long long)f * fs_in;
     bf16_t* yf = y + off_out + (long long)f * fs_out;
-    for (int p = p0 + pl; p < p1; p += lanes) {
+    int p = p0 + pl;
+    for (; p + 3 * lanes < p1; p += 4 * lanes) {
+        u32x4_t raw[4];
+        int hh[4], ww[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pp = p + u * lanes;
+            hh[u] = pp / W; ww[u] = pp - hh[u] * W;
+            raw[u] = *(const u32x4_t*)(xf + ((long long)hh[u] * Wp_in + ww[u]) * Cp_in + chunk * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v[8];
+            unpack8(raw[u], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+                v[e] = silu ? silu_f(t) : t;
+            }
+            *(u32x4_t*)(yf + ((long long)hh[u] * Wp_out + ww[u]) * Cp_out + chunk * 8) = pack8(v);
+        }
+    }
+    for (; p < p1; p += lanes) {
         const int h = p / W, w = p - h * W;
         float v[8];
         unpack8(*(const u32x4_t*)(xf + ((long long)h * Wp_in + w) * Cp_in + chunk * 8), v);
@@ -209,14 +249,23 @@ __global__ void to_uint8_kernel(const bf16_t* tile, unsigned char* out, int T, i
         if (e_ != hipSuccess) return pf_set_err(hipGetErrorString(e_)); \
     } while (0)
 
-static int pix_per_block_for(int HW) { return HW >= 65536 ? 4096 : (HW >= 4096 ? 1024 : 256); }
+// pixels per block: aim at >= ~2048 workgroups per launch (256 CUs x 8), at least 4 pixels per thread-lane
+static int pix_per_block_for(int HW, int T, int C) {
+    const int lanes = 256 / (C / 8);
+    long long want = ((long long)HW * T + 2047) / 2048;
+    const int unit = 4 * lanes;
+    long long ppb = (want + unit - 1) / unit * unit;
+    if (ppb < unit) ppb = unit;
+    if (ppb > HW) ppb = (HW + unit - 1) / unit * unit;
+    return (int)ppb;
+}
 
 extern "C" int pf_gn_stats(const void* x, double* stats, int T, int C, int Cp, int H, int W, int Hp, int Wp,
                            long long frame_stride, long long base_off, hipStream_t stream) {
     if (!x || !stats) return pf_set_err("pf_gn_stats: null operand");
     const int nch = C / 8;
     if (C % 8 || nch > 64 || (256 % nch)) return pf_set_err("pf_gn_stats: C/8 must divide 256 and C <= 512");
-    const int ppb = pix_per_block_for(H * W);
+    const int ppb = pix_per_block_for(H * W, T, C);
     hipLaunchKernelGGL(gn_stats_kernel, dim3((H * W + ppb - 1) / ppb, T), dim3(256), 0, stream, (const bf16_t*)x, stats, C, Cp,
                        H, W, Hp, Wp, frame_stride, base_off, ppb);
     CHECK_LAUNCH();
@@ -230,7 +279,7 @@ extern "C" int pf_gn_apply(const void* x, void* y, const double* stats, const fl
     if (!x || !y || !stats || !gamma || !beta) return pf_set_err("pf_gn_apply: null operand");
     const int nch = C / 8;
     if (C % 8 || nch > 64 || (256 % nch) || G > 64 || C % G) return pf_set_err("pf_gn_apply: unsupported C/G");
-    const int ppb = pix_per_block_for(H * W);
+    const int ppb = pix_per_block_for(H * W, T, C);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((H * W + ppb - 1) / ppb, T), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y,
                        stats, gamma, beta, C, Cp_in, Cp_out, G, H, W, Hp_in, Wp_in, fs_in, off_in, Hp_out, Wp_out, fs_out,
                        off_out, eps, silu, ppb);

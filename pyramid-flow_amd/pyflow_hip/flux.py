@@ -48,9 +48,12 @@ def _pad_n(w, b, mult=128):
 class FluxWeights:
     """Packs a reference-keyed state dict (SURVEY 8b key layout) into fused bf16 matrices."""
 
-    def __init__(self, sd, cfg, device):
+    def __init__(self, sd, cfg, device, head_major=False):
+        """head_major: order the fused K|V|Q output columns per head ([h][k|v|q][64]) instead of per type -- the
+        layout of the sequence-parallel exchange buffers (a rank's heads are then one contiguous column block)."""
         sd = {k: v.detach().float().cpu() for k, v in sd.items()}
         self.cfg = cfg
+        self.head_major = head_major
         H, hd = cfg["num_attention_heads"], cfg["attention_head_dim"]
         assert hd == 64, "attention kernel is specialised for head_dim 64"
         d = H * hd
@@ -64,6 +67,24 @@ class FluxWeights:
 
         def Bv(name):
             return sd[name + ".bias"]
+
+        if head_major:
+            t_, h_, e_ = torch.meshgrid(torch.arange(3), torch.arange(H), torch.arange(hd), indexing="ij")
+            perm = torch.empty(3 * d, dtype=torch.long)
+            perm[(h_ * 3 * hd + t_ * hd + e_).reshape(-1)] = (t_ * d + h_ * hd + e_).reshape(-1)
+        else:
+            perm = None
+
+        def kvq(wk, wv, wq, extra=None):
+            """fused [K; V; Q (; extra)] weight + bias, columns optionally head-major"""
+            w_ = torch.cat([W(wk), W(wv), W(wq)])
+            b_ = torch.cat([Bv(wk), Bv(wv), Bv(wq)])
+            if perm is not None:
+                w_, b_ = w_[perm], b_[perm]
+            if extra is not None:
+                w_ = torch.cat([w_, W(extra)])
+                b_ = torch.cat([b_, Bv(extra)])
+            return _bf16(w_, dev), _f32(b_, dev)
 
         # conditioning MLPs (gemv, bf16 weights / fp32 bias)
         self.t1 = (_bf16(W("time_text_embed.timestep_embedder.linear_1"), dev), _f32(Bv("time_text_embed.timestep_embedder.linear_1"), dev))
@@ -89,10 +110,8 @@ class FluxWeights:
             mod_b += [Bv(p + "norm1.linear"), Bv(p + "norm1_context.linear")]
             blk = dict(mod=off)
             off += 12 * d
-            blk["kvq_img"] = (_bf16(torch.cat([W(p + "attn.to_k"), W(p + "attn.to_v"), W(p + "attn.to_q")]), dev),
-                              _f32(torch.cat([Bv(p + "attn.to_k"), Bv(p + "attn.to_v"), Bv(p + "attn.to_q")]), dev))
-            blk["kvq_txt"] = (_bf16(torch.cat([W(p + "attn.add_k_proj"), W(p + "attn.add_v_proj"), W(p + "attn.add_q_proj")]), dev),
-                              _f32(torch.cat([Bv(p + "attn.add_k_proj"), Bv(p + "attn.add_v_proj"), Bv(p + "attn.add_q_proj")]), dev))
+            blk["kvq_img"] = kvq(p + "attn.to_k", p + "attn.to_v", p + "attn.to_q")
+            blk["kvq_txt"] = kvq(p + "attn.add_k_proj", p + "attn.add_v_proj", p + "attn.add_q_proj")
             blk["o_img"] = (_bf16(W(p + "attn.to_out.0"), dev), _f32(Bv(p + "attn.to_out.0"), dev))
             blk["o_txt"] = (_bf16(W(p + "attn.to_add_out"), dev), _f32(Bv(p + "attn.to_add_out"), dev))
             blk["ff1_img"] = (_bf16(W(p + "ff.net.0.proj"), dev), _f32(Bv(p + "ff.net.0.proj"), dev))
@@ -108,8 +127,7 @@ class FluxWeights:
             mod_b.append(Bv(p + "norm.linear"))
             blk = dict(mod=off)
             off += 3 * d
-            blk["kvqm"] = (_bf16(torch.cat([W(p + "attn.to_k"), W(p + "attn.to_v"), W(p + "attn.to_q"), W(p + "proj_mlp")]), dev),
-                           _f32(torch.cat([Bv(p + "attn.to_k"), Bv(p + "attn.to_v"), Bv(p + "attn.to_q"), Bv(p + "proj_mlp")]), dev))
+            blk["kvqm"] = kvq(p + "attn.to_k", p + "attn.to_v", p + "attn.to_q", extra=p + "proj_mlp")
             blk["out"] = (_bf16(W(p + "proj_out"), dev), _f32(Bv(p + "proj_out"), dev))
             blk["norm_q"] = _f32(sd[p + "attn.norm_q.weight"], dev)
             blk["norm_k"] = _f32(sd[p + "attn.norm_k.weight"], dev)
@@ -128,12 +146,15 @@ class FluxWeights:
 
 
 class FluxEngine:
+    HEAD_MAJOR = False
+
     def __init__(self, state_dict, cfg, device="cuda"):
         self.dev = torch.device(device)
-        self.w = FluxWeights(state_dict, cfg, self.dev)
+        self.w = FluxWeights(state_dict, cfg, self.dev, head_major=self.HEAD_MAJOR)
         self.cfg = cfg
         self._ws = {}
         self._ctx = None
+        self._mod_cache = None
 
     # ---- workspace (grow-only) ----
     def _buf(self, name, numel, dtype):
@@ -157,6 +178,7 @@ class FluxEngine:
         ops.gemm(x, w.ctx_w, out, B * Lt, w.d, w.ctx_k, w.ctx_k, w.ctx_k, w.d, bias=w.ctx_b)
         self._ctx = out
         self._ctx_keep = x
+        self._mod_cache = {}          # conditioning depends on (timestep, pooled): new prompt -> new cache
         return out
 
     def conditioning(self, timesteps, pooled):
@@ -164,6 +186,13 @@ class FluxEngine:
         w = self.w
         B = len(timesteps)
         d = w.d
+        # the modulation vectors are a function of (timestep, pooled prompt) only: every later unit repeats the
+        # (stage, step) timesteps of unit 1, so 870 of the 960 forwards of a video hit this cache (1.07 GB of AdaLN
+        # weights not re-read per forward).  Keyed on the timestep values and the pooled tensor's identity.
+        key = (tuple(float(t) for t in timesteps), pooled.data_ptr(), pooled._version)
+        cache = getattr(self, "_mod_cache", None)
+        if cache is not None and key in cache:
+            return cache[key], None
         tproj = self._buf("tproj", B * 256, torch.float32).view(B, 256)
         ops.timestep_embed(tproj, timesteps, 256)
         h1 = self._buf("h1", B * d, torch.float32)
@@ -177,6 +206,9 @@ class FluxEngine:
         ops.gemv(w.p2[0], w.p2[1], h1, temb, d, d, B, silu_in=True, accumulate=True)
         mod = self._buf("mod", B * w.n_mod, torch.float32)
         ops.gemv(w.mod_w, w.mod_b, temb, mod, w.n_mod, d, B, silu_in=True)
+        if cache is not None and len(cache) < 256:
+            mod = mod[:B * w.n_mod].clone()
+            cache[key] = mod
         return mod, temb
 
     def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):

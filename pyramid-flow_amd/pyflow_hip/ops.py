@@ -67,15 +67,19 @@ def gemm_set_policy(force):
 LOG2E = 1.4426950408889634
 
 
-def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale, q_prescaled=False):
+def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale, q_prescaled=False,
+              head_stride_qk=0, ldo=None, o_bstride=None):
     lib = L.load()
     d = AttnDesc()
     d.Q = Q.data_ptr() + 2 * q_off
     d.K = K.data_ptr() + 2 * k_off
     d.Vt = Vt.data_ptr()
     d.O = O.data_ptr() + 2 * o_off
-    d.ldq = d.ldk = d.ldo = ld
-    d.strideQ = d.strideK = d.strideO = bstride
+    d.ldq = d.ldk = ld
+    d.ldo = ld if ldo is None else ldo
+    d.strideQ = d.strideK = bstride
+    d.strideO = bstride if o_bstride is None else o_bstride
+    d.head_stride_qk = head_stride_qk
     d.strideVt_b = H * 64 * Lp
     d.strideVt_h = 64 * Lp
     d.B, d.H, d.L, d.Lp, d.Lt = B, H, Lseq, Lp, Lt
@@ -87,11 +91,11 @@ def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt,
                     lambda: check(lib.pf_attention_bf16(C.byref(d), stream())))
 
 
-def v_transpose(V, Vt, v_off, ldv, strideV, B, H, Lseq, Lp):
+def v_transpose(V, Vt, v_off, ldv, strideV, B, H, Lseq, Lp, head_stride=0):
     lib = L.load()
     check(lib.pf_v_transpose(C.c_void_p(V.data_ptr() + 2 * v_off), ptr(Vt), C.c_int(ldv), C.c_longlong(strideV),
                              C.c_longlong(H * 64 * Lp), C.c_longlong(64 * Lp), C.c_int(B), C.c_int(H),
-                             C.c_int(Lseq), C.c_int(Lp), stream()))
+                             C.c_int(Lseq), C.c_int(Lp), C.c_int(head_stride), stream()))
 
 
 def ln_modulate(x, y, shift, scale, D, B, rows, x_bstride, y_bstride, ldx, ldy, mod_bstride,
@@ -107,11 +111,11 @@ def ln_modulate(x, y, shift, scale, D, B, rows, x_bstride, y_bstride, ldx, ldy, 
 
 
 def qk_norm_rope(qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt, wk_txt, rope, B, Lseq, Lt, H, eps=1e-6,
-                 q_scale=1.0):
+                 q_scale=1.0, head_stride=0):
     lib = L.load()
     check(lib.pf_qk_norm_rope(ptr(qkv), C.c_int(ld), C.c_longlong(bstride), C.c_int(q_off), C.c_int(k_off),
                               ptr(wq_img), ptr(wk_img), ptr(wq_txt), ptr(wk_txt), ptr(rope), C.c_int(B),
-                              C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), C.c_float(q_scale), stream()))
+                              C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), C.c_float(q_scale), C.c_int(head_stride), stream()))
 
 
 def gemv(W, bias, x, y, N, K, B, ldw=None, ldx=None, ldy=None, silu_in=False, accumulate=False, y_off=0):

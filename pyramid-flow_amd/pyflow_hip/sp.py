@@ -1,0 +1,179 @@
+"""Sequence parallelism for the DiT (Ulysses-style): process-group plumbing and the partition tables.
+
+Replaces trainer_misc/sp_utils.py:14-98 (group bookkeeping) and trainer_misc/communicate.py:7-66 (the list-form
+all_to_all built from tensor_split + contiguous copies + cat) of the reference.  Differences by design
+(SURVEY 2.3 / 8e): ONE token layout for all 24 blocks (contiguous row chunks of the merged [text | image]
+sequence per rank -- the reference's batch-scatter re-partition between double and single blocks, which limits it
+to P = 2, does not exist), an UNEVEN head map (H = 30 heads over 4 or 8 ranks), exchange buffers laid out so that
+each all-to-all is a single `all_to_all_single` with split sizes and needs no cat / split copies on the receiving
+side, and no replicated-table exchanges (C4-C6: every rank derives RoPE tables and the implicit mask locally).
+
+torch.distributed is plumbing here: backend "nccl" is RCCL over xGMI on the GPU box.  For tests the same code runs
+over "gloo" (CPU tensors directly, device tensors staged through the host) because gloo has no all_to_all.
+"""
+import torch
+import torch.distributed as dist
+
+
+def even_split(n, parts):
+    """n items over `parts` ranks, sizes differing by at most one (first n % parts ranks get the extra item)."""
+    base, rem = divmod(n, parts)
+    return [base + (1 if p < rem else 0) for p in range(parts)]
+
+
+def starts_of(counts):
+    out, s = [], 0
+    for c in counts:
+        out.append(s)
+        s += c
+    return out
+
+
+class SPLayout:
+    """Partition of one stage sequence (L rows, first Lt text) and of the H heads over P ranks."""
+
+    HEAD_COLS = 192          # head-major exchange layout: per head [k(64) | v(64) | q(64)]
+
+    def __init__(self, L, Lt, H, P, rank):
+        self.L, self.Lt, self.H, self.P, self.rank = L, Lt, H, P, rank
+        self.rows = even_split(L, P)
+        self.row0 = starts_of(self.rows)
+        self.heads = even_split(H, P)
+        self.head0 = starts_of(self.heads)
+        self.r0 = self.row0[rank]
+        self.nloc = self.rows[rank]
+        self.r1 = self.r0 + self.nloc
+        self.n_txt = min(max(Lt - self.r0, 0), self.nloc)      # local text rows come first
+        self.n_img = self.nloc - self.n_txt
+        self.img0 = max(self.r0, Lt) - Lt                       # first local image token (index into the clip-concatenated tokens)
+        self.my_heads = self.heads[rank]
+        self.my_cols = self.my_heads * self.HEAD_COLS
+
+    # element counts of the two exchanges, for a CFG batch of B
+    def a2a1_splits(self, B):
+        """qkv exchange: I send my rows x the peer's heads; I receive the peer's rows x my heads."""
+        send = [self.nloc * B * h * self.HEAD_COLS for h in self.heads]
+        recv = [r * B * self.my_cols for r in self.rows]
+        return send, recv
+
+    def a2a2_splits(self, B):
+        """attention-output exchange: I send the peer's rows x my heads; I receive my rows x the peer's heads."""
+        send = [r * B * self.my_heads * 64 for r in self.rows]
+        recv = [self.nloc * B * h * 64 for h in self.heads]
+        return send, recv
+
+
+class LocalComm:
+    """world of one: the exchanges are plain device copies (used to test the SP code path on a single GPU)."""
+    rank, world = 0, 1
+
+    def all_to_all(self, recv, send, recv_splits, send_splits):
+        recv[:send.numel()].copy_(send)
+
+    def all_reduce(self, t):
+        return t
+
+    def broadcast(self, t, src=0):
+        return t
+
+    def barrier(self):
+        pass
+
+
+class SPComm:
+    """all-to-all / all-reduce / broadcast over one torch.distributed group (the SP group = consecutive ranks,
+    sp_utils.py:42-47; inference uses world_size == sp_group_size, inference_multigpu.py:36)."""
+
+    def __init__(self, group=None):
+        assert dist.is_initialized(), "init the process group first (trainer_misc/utils.py:71-106 contract: env://)"
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.native = self.backend == "nccl"          # RCCL: device-side all_to_all_single with split sizes
+
+    def _global(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def all_to_all(self, recv, send, recv_splits, send_splits):
+        """recv / send: flat 1-D tensors; splits in elements, indexed by group rank."""
+        if self.native:
+            dist.all_to_all_single(recv[:sum(recv_splits)], send[:sum(send_splits)], recv_splits, send_splits,
+                                   group=self.group)
+            return
+        # gloo: no all_to_all; emulate with point-to-point (device tensors staged through the host)
+        dev = send.device
+        hs = send[:sum(send_splits)].cpu() if dev.type != "cpu" else send
+        hr = torch.empty(sum(recv_splits), dtype=recv.dtype)
+        so, ro = starts_of(send_splits), starts_of(recv_splits)
+        ops = []
+        for p in range(self.world):
+            if p == self.rank:
+                hr[ro[p]:ro[p] + recv_splits[p]].copy_(hs[so[p]:so[p] + send_splits[p]])
+                continue
+            if send_splits[p]:
+                ops.append(dist.P2POp(dist.isend, hs[so[p]:so[p] + send_splits[p]], self._global(p), self.group))
+            if recv_splits[p]:
+                ops.append(dist.P2POp(dist.irecv, hr[ro[p]:ro[p] + recv_splits[p]], self._global(p), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        recv[:hr.numel()].copy_(hr)
+
+    def all_reduce(self, t):
+        if self.native or t.device.type == "cpu":
+            dist.all_reduce(t, group=self.group)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        return t
+
+    def broadcast(self, t, src=0):
+        if self.native or t.device.type == "cpu":
+            dist.broadcast(t, self._global(src), group=self.group)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, self._global(src), group=self.group)
+            t.copy_(h)
+        return t
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+# ---- reference-named helpers (trainer_misc/sp_utils.py) ---------------------------------------------------------
+_SP = None
+
+
+def init_sequence_parallel_group(args=None, sp_group_size=None):
+    """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world)."""
+    global _SP
+    world = dist.get_world_size()
+    size = sp_group_size or getattr(args, "sp_group_size", None) or world
+    assert world % size == 0
+    rank = dist.get_rank()
+    group = None
+    if size != world:
+        for g0 in range(0, world, size):
+            grp = dist.new_group(list(range(g0, g0 + size)))
+            if g0 <= rank < g0 + size:
+                group = grp
+    _SP = SPComm(group)
+    return _SP
+
+
+def is_sequence_parallel_initialized():
+    return _SP is not None
+
+
+def get_sequence_parallel_comm():
+    return _SP
+
+
+def get_sequence_parallel_world_size():
+    return _SP.world if _SP else 1
+
+
+def get_sequence_parallel_rank():
+    return _SP.rank if _SP else 0

@@ -1,0 +1,62 @@
+"""worker of tests/test_sp_gpu.py: one rank of a P-process sequence-parallel miniFLUX forward.
+All ranks share cuda:0 (the GPU box has one GPU); the exchange runs over gloo staged through the host, i.e. the
+same SPComm code path as RCCL except for the transport.  Rank 0 also runs the single-process engine and compares."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out_path = sys.argv[1]
+    heads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from pyflow_hip import synth
+    from pyflow_hip.flux import FluxEngine
+    from pyflow_hip.flux_sp import FluxEngineSP
+    from pyflow_hip.sp import init_sequence_parallel_group
+    from util import rel_l2, round_sd
+    comm = init_sequence_parallel_group(sp_group_size=world)
+    cfg = dict(synth.TINY_FLUX, num_attention_heads=heads)
+    sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05, lively=True))
+    g = torch.Generator().manual_seed(0)
+    shapes = [(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)]
+    clips = [torch.randn(2, 16, *s, generator=g).to(torch.bfloat16).float().cuda() for s in shapes]
+    enc = torch.randn(2, 16, 32, generator=g).to(torch.bfloat16).float()
+    mask = torch.zeros(2, 16, dtype=torch.long)
+    mask[0, :5] = 1
+    mask[1, :12] = 1
+    pooled = torch.randn(2, 16, generator=g)
+    t = [704.0, 704.0]
+    eng = FluxEngineSP(sd, cfg, "cuda", comm=comm)
+    plan = eng.make_plan(shapes, mask)
+    eng.encode_context(enc)
+    v = eng.forward_tokens(plan, clips, t, pooled).clone()
+    torch.cuda.synchronize()
+    ok = True
+    if rank == 0:
+        ref_eng = FluxEngine(sd, cfg, "cuda")
+        ref_eng.encode_context(enc)
+        ref = ref_eng.forward_tokens(plan, clips, t, pooled).clone()
+        err = rel_l2(v.cpu(), ref.cpu())
+        ok = err < 2e-3
+        with open(out_path, "w") as f:
+            f.write(f"{err:.3e} {int(ok)} world={world} heads={heads} lay_rows={eng.layout(plan).rows} lay_heads={eng.layout(plan).heads}\n")
+    # all ranks must hold the same replicated result
+    gathered = [torch.empty_like(v.cpu()) for _ in range(world)]
+    dist.all_gather(gathered, v.cpu())
+    same = all(torch.equal(gathered[0], x) for x in gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if (ok and same) else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""CPU tests of the sequence-parallel plumbing (pyflow_hip/sp.py): partition tables and the uneven all-to-all over
+gloo (world size 2 and 3), against a single-process restatement of what each exchange must deliver."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_layout_tables():
+    from pyflow_hip.sp import SPLayout, even_split
+    assert even_split(30, 8) == [4, 4, 4, 4, 4, 4, 3, 3]
+    assert even_split(30, 4) == [8, 8, 7, 7]
+    L, Lt, H, P = 15488, 128, 30, 8
+    lays = [SPLayout(L, Lt, H, P, r) for r in range(P)]
+    assert sum(l.nloc for l in lays) == L and sum(l.my_heads for l in lays) == H
+    assert [l.r0 for l in lays] == [1936 * r for r in range(P)]
+    assert lays[0].n_txt == 128 and lays[0].n_img == 1936 - 128 and lays[1].n_txt == 0
+    assert lays[1].img0 == 1936 - 128
+    B = 2
+    for r in range(P):
+        s1, r1 = lays[r].a2a1_splits(B)
+        for p in range(P):       # what r sends to p is what p expects from r
+            assert s1[p] == lays[p].a2a1_splits(B)[1][r]
+        s2, r2 = lays[r].a2a2_splits(B)
+        for p in range(P):
+            assert s2[p] == lays[p].a2a2_splits(B)[1][r]
+    # text rows spread over several ranks when the chunk is shorter than the text
+    small = [SPLayout(300, 128, 4, 3, r) for r in range(3)]
+    assert [l.n_txt for l in small] == [100, 28, 0] and [l.n_img for l in small] == [0, 72, 100]
+
+
+def _worker(rank, world, port, H, L, Lt, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyflow_hip.sp import SPLayout, init_sequence_parallel_group
+    comm = init_sequence_parallel_group(sp_group_size=world)
+    lay = SPLayout(L, Lt, H, world, rank)
+    # global "qkv" value of (row, b, head, col) -- every rank can evaluate any entry
+    def val(rows, heads, cols):
+        r = torch.arange(rows[0], rows[1])[:, None, None, None].float()
+        b = torch.arange(B)[None, :, None, None].float()
+        h = torch.arange(heads[0], heads[1])[None, None, :, None].float()
+        c = torch.arange(cols)[None, None, None, :].float()
+        return r * 1000 + b * 500 + h * 10 + c * 0.01
+    # exchange 1: send chunks [dest][my rows][b][dest heads x 192]
+    send = torch.cat([val((lay.r0, lay.r1), (lay.head0[p], lay.head0[p] + lay.heads[p]), 192).reshape(-1) for p in range(world)])
+    s_spl, r_spl = lay.a2a1_splits(B)
+    recv = torch.empty(sum(r_spl))
+    comm.all_to_all(recv, send, r_spl, s_spl)
+    exp = val((0, L), (lay.head0[rank], lay.head0[rank] + lay.my_heads), 192).reshape(-1)
+    ok1 = torch.equal(recv, exp)
+    # exchange 2: send [dest rows][b][my heads x 64]; receive [src][my rows][b][src heads x 64]
+    send2 = val((0, L), (lay.head0[rank], lay.head0[rank] + lay.my_heads), 64).reshape(-1)
+    s_spl, r_spl = lay.a2a2_splits(B)
+    recv2 = torch.empty(sum(r_spl))
+    comm.all_to_all(recv2, send2, r_spl, s_spl)
+    exp2 = torch.cat([val((lay.r0, lay.r1), (lay.head0[p], lay.head0[p] + lay.heads[p]), 64).reshape(-1) for p in range(world)])
+    ok2 = torch.equal(recv2, exp2)
+    t = torch.full((4,), float(rank + 1))
+    comm.all_reduce(t)
+    ok3 = bool((t == sum(range(1, world + 1))).all())
+    bc = torch.full((3,), float(rank))
+    comm.broadcast(bc, 0)
+    ok4 = bool((bc == 0).all())
+    q.put((rank, ok1, ok2, ok3, ok4))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,L", [(2, 3, 37), (3, 4, 50)])
+def test_uneven_all_to_all_over_gloo(world, H, L):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, L, 16, 2, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(all(r[1:]) for r in res), res

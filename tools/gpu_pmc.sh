@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 REPO=$(pwd)
-SCRIPT=$1; TAG=$2
+SCRIPT=$1; TAG=$2; ONLY=${3:-all}
 cd /tmp
 i=0
 for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
@@ -11,7 +11,8 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INSTS_VMEM" \
             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- python $REPO/$SCRIPT 3 > /tmp/pmc_${TAG}_$i.log 2>&1
+  if [ "$ONLY" = "traffic" ] && [ $i -lt 4 ]; then continue; fi
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc_${TAG}_$i -o p --output-format csv -- python $REPO/$SCRIPT 2 > /tmp/pmc_${TAG}_$i.log 2>&1
   f=$(find /tmp/pmc_${TAG}_$i -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then python $REPO/tools/pmc_summarize.py $f >> $REPO/gpurun_out/pmc/${TAG}.txt; else echo "pass $i failed: $(tail -3 /tmp/pmc_${TAG}_$i.log)" >> $REPO/gpurun_out/pmc/${TAG}.txt; fi
 done
