@@ -5,7 +5,9 @@ weights of the released architecture.
 
 A "step" = one complete video: generate() -> uint8 frames resident on the device (text encoding excluded, as in
 SURVEY 8d).  python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
-N > 1 (round 1): independent replicas, one video per rank ("weak"); sequence parallelism is the next row.
+N > 1: ONE video per step sampled by all N GPUs together -- sequence-parallel DiT (Ulysses all-to-all over RCCL,
+pyflow_hip/flux_sp.py) + tile-parallel VAE decode, frames assembled on rank 0 ("scaling": "strong");
+`--parallelism replicas` instead runs N independent videos (no data-path collective, "weak").
 """
 import argparse
 import json
@@ -126,18 +128,27 @@ def main():
     ap.add_argument("--tiny-model", action="store_true", help="tiny random model (plumbing check, not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-period", type=int, default=7)
+    ap.add_argument("--parallelism", default="sp", choices=["sp", "replicas"],
+                    help="N > 1: sp = one video across all GPUs (default), replicas = one video per GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    use_sp = world > 1 and args.parallelism == "sp"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # PF_DIST_BACKEND=gloo: plumbing test of the N > 1 path on a box with fewer GPUs than ranks (tests only)
+        dist.init_process_group(os.environ.get("PF_DIST_BACKEND", "nccl"))
+        if use_sp:      # must exist before the model is built (reference contract, inference_multigpu.py:34-39)
+            from pyflow_hip.sp import init_sequence_parallel_group
+            init_sequence_parallel_group(sp_group_size=world)
 
     H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
     pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model)
@@ -170,7 +181,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     sp.active = False
-    assert out.shape == (frames_per_video, H, W, 3) and out.dtype == torch.uint8
+    if rank == 0 or not use_sp:
+        assert out.shape == (frames_per_video, H, W, 3) and out.dtype == torch.uint8
+    else:
+        assert out is None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -190,19 +204,33 @@ def main():
                    avg_launch_ms=round(s["ms_total"] / s["launches"], 4))
         if name == "gemm":
             roof = rec
+            try:     # HBM traffic of the dominant kernel: rocprofv3 --pmc passes committed under profiles/
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
+                    pm = json.load(f)["kernels"]
+                k = next(v for n, v in pm.items() if "gemm256_kernel<192" in n)
+                rec["traffic"] = round(k["hbm_bytes_per_launch"])
+                rec["traffic_note"] = ("bytes per launch of gemm256_kernel<192> = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), mean "
+                                       "over the launches of a full-width forward at L=15488 (profiles/r01_pmc_forward_maxL.json); "
+                                       "counted at the L2<->fabric interface incl. Infinity-Cache hits")
+            except Exception:
+                pass
         else:
             extra[name] = rec
-    value = frames_per_video * args.steps * world / dt
+    value = frames_per_video * args.steps * (1 if use_sp else world) / dt
     res = {
         "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling",
         "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True,
+        "scaling": "strong" if use_sp else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: miniFLUX pyramid DiT (1.97 B params, 8+16 blocks, d=1920) + CausalVideoVAE "
                                f"tiled(256)/chunked(1) decode, {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
                                "CFG 7.0/5.0, random-init weights, synthetic prompt embeddings"
                                + (" [TINY MODEL: plumbing only]" if args.tiny_model else ""),
-                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one video per GPU)"},
+                   "parallelism": "single GPU" if world == 1 else (
+                       f"sp{world}: one video over {world} GPUs, sequence-parallel DiT (all-to-all heads<->rows over RCCL, "
+                       "uneven 30-head map) + tile-parallel VAE decode" if use_sp
+                       else f"{world} independent replicas (one video per GPU)")},
         "roofline": roof,
         "roofline_other_kernels": extra,
     }

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import sp as sp_mod
 from .flux import FluxEngine
 from .scheduler import PyramidFlowMatchEulerDiscreteScheduler
 
@@ -62,7 +63,15 @@ class PyramidDiTForVideoGeneration:
         self._device = torch.device(device)
         if dit_state_dict is None:
             dit_state_dict, dit_config = _load_diffusers_dir(os.path.join(model_path, model_variant))
-        self.dit = FluxEngine(dit_state_dict, dit_config, device)
+        # like the reference (flux_block.py:734-743), the sequence-parallel form is chosen at construction time:
+        # init_sequence_parallel_group() must have run before the model is built
+        self.sp = sp_mod.get_sequence_parallel_comm() if sp_mod.is_sequence_parallel_initialized() else None
+        if self.sp is not None and self.sp.world > 1:
+            from .flux_sp import FluxEngineSP
+            self.dit = FluxEngineSP(dit_state_dict, dit_config, device, comm=self.sp)
+        else:
+            self.sp = None
+            self.dit = FluxEngine(dit_state_dict, dit_config, device)
         self.dit.config = type("Cfg", (), dict(dit_config))()
         self.text_encoder = text_encoder
         self.load_text_encoder = load_text_encoder
@@ -180,6 +189,8 @@ class PyramidDiTForVideoGeneration:
                 alpha = 1 / (math.sqrt(1 + (1 / gamma)) * (1 - ori_sigma) + ori_sigma)
                 beta = alpha * (1 - ori_sigma) / math.sqrt(gamma)
                 noise = self.sample_block_noise(1, C, 1, h, w).to(self._device, torch.float32).contiguous()
+                if self.sp is not None:          # rank-local RNG streams may differ: rank 0's draw is the one used
+                    self.sp.broadcast(noise, 0)
                 xn = torch.empty(C, 1, h, w, dtype=torch.float32, device=self._device)
                 ops.renoise_upsample(x, noise, xn, C, h, w, alpha, beta, self._round)
                 x = xn
@@ -238,6 +249,8 @@ class PyramidDiTForVideoGeneration:
         C = self.dit.w.out_cols // 4
         latents = self.prepare_latents(1, C, temp, height, width, pe.dtype, self._device, generator)
         x = latents[0].to(self._device, torch.float32).contiguous()                 # [C,T,H,W]
+        if self.sp is not None:              # pipeline.py:1089-1095 / 752-756: one broadcast instead of one per step
+            self.sp.broadcast(x, 0)
         for _ in range(n_st - 1):                                                     # :1112-1116
             Cc, T, H, W = x.shape
             y = torch.empty(Cc, T, H // 2, W // 2, dtype=torch.float32, device=self._device)
@@ -269,7 +282,8 @@ class PyramidDiTForVideoGeneration:
     @torch.no_grad()
     def decode_latent(self, latents, save_memory=True, inference_multigpu=False, output_type="pil"):
         """:1221-1243.  Returns list[PIL] (or uint8 [T,H,W,3] tensor for output_type='uint8')."""
-        if inference_multigpu and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+        if self.sp is None and inference_multigpu and torch.distributed.is_initialized() \
+                and torch.distributed.get_rank() != 0:
             return None
         if self.vae is None:
             raise RuntimeError("VAE not loaded")
@@ -277,11 +291,16 @@ class PyramidDiTForVideoGeneration:
         # un-normalisation (:1226-1230) is folded into the latent -> channels-last load of the decoder
         aff = (1.0 / self.vae_scale_factor, self.vae_shift_factor,
                1.0 / self.vae_video_scale_factor, self.vae_video_shift_factor)
+        # with a sequence-parallel group the decode is tile-parallel over the same ranks (the reference leaves every
+        # rank but 0 idle here, pipeline.py:1223-1224); frames are assembled on rank 0, other ranks return None
+        comm = self.sp if (self.sp is not None and self.vae.use_tiling) else None
+        if self.sp is not None and comm is None and self.sp.rank != 0:
+            return None
         if save_memory:
-            u8 = self.vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256, affine=aff)
+            u8 = self.vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256, affine=aff, comm=comm)
         else:
-            u8 = self.vae.decode_to_uint8(z, window_size=2, tile_sample_min_size=512, affine=aff)
-        if output_type == "uint8":
+            u8 = self.vae.decode_to_uint8(z, window_size=2, tile_sample_min_size=512, affine=aff, comm=comm)
+        if u8 is None or output_type == "uint8":
             return u8
         arr = u8.cpu().numpy()
         from PIL import Image

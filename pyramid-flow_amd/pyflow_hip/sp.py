@@ -79,6 +79,12 @@ class LocalComm:
     def barrier(self):
         pass
 
+    def send(self, t, dst):
+        raise RuntimeError("LocalComm has no peers")
+
+    def recv(self, t, src):
+        raise RuntimeError("LocalComm has no peers")
+
 
 class SPComm:
     """all-to-all / all-reduce / broadcast over one torch.distributed group (the SP group = consecutive ranks,
@@ -140,6 +146,22 @@ class SPComm:
 
     def barrier(self):
         dist.barrier(group=self.group)
+
+    def send(self, t, dst):
+        """point-to-point (halo / strip exchange); stream-ordered on RCCL, blocking on gloo"""
+        if self.native or t.device.type == "cpu":
+            dist.send(t.contiguous(), self._global(dst), group=self.group)
+        else:
+            dist.send(t.contiguous().cpu(), self._global(dst), group=self.group)
+
+    def recv(self, t, src):
+        if self.native or t.device.type == "cpu":
+            dist.recv(t, self._global(src), group=self.group)
+        else:
+            h = torch.empty(t.shape, dtype=t.dtype)
+            dist.recv(h, self._global(src), group=self.group)
+            t.copy_(h)
+        return t
 
 
 # ---- reference-named helpers (trainer_misc/sp_utils.py) ---------------------------------------------------------

@@ -382,66 +382,128 @@ class CausalVideoVAE:
         assert fo == T_out, (fo, T_out)
         return out
 
+    def _blend(self, a, b, blend, vertical, a_w=None):
+        """blend_v / blend_h (:397-407): b updated in place from the bottom rows / right columns of a."""
+        lib = L.load()
+        Tt, Hb, Wb, _ = b.shape
+        check(lib.pf_blend_tiles(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_int(Tt),
+                                 C.c_int(a.shape[1]), C.c_int(a.shape[2] if a_w is None else a_w), C.c_int(Hb), C.c_int(Wb),
+                                 C.c_int(8), C.c_int(blend), C.c_int(int(vertical)), stream()))
+
     @torch.no_grad()
-    def decode_tiles(self, z, temporal_chunk, window_size, tile_sample_min_size, affine=(1.0, 0.0, 1.0, 0.0)):
-        """z [1,C,T,h,w] fp32 -> (tiles grid, geometry) following decode/tiled_decode (:376-395, 468-519)."""
+    def decode_tiles(self, z, temporal_chunk, window_size, tile_sample_min_size, affine=(1.0, 0.0, 1.0, 0.0), comm=None):
+        """z [1,C,T,h,w] fp32 -> (tiles grid, geometry) following decode/tiled_decode (:376-395, 468-519).
+
+        comm (SPComm with world > 1): tile-parallel decode -- the tile COLUMNS are split into contiguous blocks over
+        the ranks (the reference decodes on rank 0 only, pipeline.py:1223-1224).  Tiles are independent until the
+        blend; blend_v is column-local, blend_h needs the right 64-px strip of the left neighbour AFTER its vertical
+        blend, which crosses a rank boundary once per tile row: rank r receives that strip from r-1 and forwards its own
+        (a 4-step pipeline of point-to-point messages).  Same arithmetic in the same per-element order as the
+        sequential loop, so the result is bit-identical.  Returns this rank's column block (col0, rows-of-tiles)."""
         assert z.shape[0] == 1, "batch size 1"
         z = z[0].to(self.dev, torch.float32).contiguous()
         Cc, T, H, W = z.shape
         tl = int(tile_sample_min_size / self.downsample_scale)
         sizes = tuple(self.chunk_sizes(T, window_size, temporal_chunk))
         if not (self.use_tiling and (W > tl or H > tl)):
+            if comm is not None and comm.world > 1 and comm.rank != 0:
+                return None, None                  # nothing to split: rank 0 decodes alone (reference behaviour)
             return [[self._decode_tile(z, 0, 0, H, W, sizes, affine)]], None
         overlap = int(tl * 0.75)
         blend = int(tile_sample_min_size * 0.25)
         limit = tile_sample_min_size - blend
-        rows = []
-        for i in range(0, H, overlap):
-            rows.append([self._decode_tile(z, i, j, min(tl, H - i), min(tl, W - j), sizes, affine)
-                         for j in range(0, W, overlap)])
-        lib = L.load()
+        i_list = list(range(0, H, overlap))
+        j_list = list(range(0, W, overlap))
+        world = comm.world if comm is not None else 1
+        rank = comm.rank if comm is not None else 0
+        from .sp import even_split, starts_of
+        ncols = even_split(len(j_list), world)
+        c0 = starts_of(ncols)[rank]
+        my_js = j_list[c0:c0 + ncols[rank]]
+        self.tile_cols = (c0, ncols[rank], len(j_list))
+        rows = [[self._decode_tile(z, i, j, min(tl, H - i), min(tl, W - j), sizes, affine) for j in my_js] for i in i_list]
+        has_left = world > 1 and c0 > 0 and ncols[rank] > 0
+        # the next rank that owns columns (ranks beyond the column count own none)
+        nxt = rank + 1 if (world > 1 and rank + 1 < world and ncols[rank + 1] > 0 and ncols[rank] > 0) else None
         for i, row in enumerate(rows):
             for j, tile in enumerate(row):
-                Tt, Hb, Wb, _ = tile.shape
                 if i > 0:
-                    a = rows[i - 1][j]
-                    check(lib.pf_blend_tiles(C.c_void_p(a.data_ptr()), C.c_void_p(tile.data_ptr()), C.c_int(Tt),
-                                             C.c_int(a.shape[1]), C.c_int(a.shape[2]), C.c_int(Hb), C.c_int(Wb), C.c_int(8),
-                                             C.c_int(blend), C.c_int(1), stream()))
+                    self._blend(rows[i - 1][j], tile, blend, True)
+                if nxt is not None and j == len(row) - 1:
+                    comm.send(tile[:, :, tile.shape[2] - blend:, :], nxt)      # right strip, after the vertical blend
                 if j > 0:
-                    a = row[j - 1]
-                    check(lib.pf_blend_tiles(C.c_void_p(a.data_ptr()), C.c_void_p(tile.data_ptr()), C.c_int(Tt),
-                                             C.c_int(a.shape[1]), C.c_int(a.shape[2]), C.c_int(Hb), C.c_int(Wb), C.c_int(8),
-                                             C.c_int(blend), C.c_int(0), stream()))
+                    self._blend(row[j - 1], tile, blend, False)
+                elif has_left:
+                    strip = torch.empty(tile.shape[0], tile.shape[1], blend, 8, dtype=torch.bfloat16, device=self.dev)
+                    comm.recv(strip, rank - 1)
+                    self._blend(strip, tile, blend, False)
         return rows, limit
 
     @torch.no_grad()
-    def decode_to_uint8(self, z, window_size=1, tile_sample_min_size=256, temporal_chunk=True, affine=(1.0, 0.0, 1.0, 0.0)):
-        """fused decode + (x*127.5+127.5).clamp.byte -> uint8 [T,H,W,3] on device (pipeline.py:1234-1240)."""
-        rows, limit = self.decode_tiles(z, temporal_chunk, window_size, tile_sample_min_size, affine)
+    def decode_to_uint8(self, z, window_size=1, tile_sample_min_size=256, temporal_chunk=True, affine=(1.0, 0.0, 1.0, 0.0),
+                        comm=None):
+        """fused decode + (x*127.5+127.5).clamp.byte -> uint8 [T,H,W,3] on device (pipeline.py:1234-1240).
+        With comm (world > 1) every rank decodes its block of tile columns and rank 0 assembles the frames
+        (returns None elsewhere, like the reference's non-zero ranks)."""
+        rows, limit = self.decode_tiles(z, temporal_chunk, window_size, tile_sample_min_size, affine, comm=comm)
         lib = L.load()
-        T_out = rows[0][0].shape[0]
+        if rows is None:
+            return None
         if limit is None:
             t = rows[0][0]
+            T_out = t.shape[0]
             H, W = t.shape[1], t.shape[2]
             out = torch.empty(T_out, H, W, 3, dtype=torch.uint8, device=self.dev)
             check(lib.pf_to_uint8(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(T_out), C.c_int(H), C.c_int(W),
                                   C.c_int(8), C.c_int(H), C.c_int(W), C.c_int(H), C.c_int(W), C.c_int(0), C.c_int(0), stream()))
             return out
-        hs = [min(r[0].shape[1], limit) for r in rows]
-        ws = [min(t.shape[2], limit) for t in rows[0]]
-        H, W = sum(hs), sum(ws)
-        out = torch.empty(T_out, H, W, 3, dtype=torch.uint8, device=self.dev)
-        y0 = 0
-        for i, row in enumerate(rows):
-            x0 = 0
-            for j, t in enumerate(row):
-                check(lib.pf_to_uint8(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(T_out), C.c_int(t.shape[1]),
-                                      C.c_int(t.shape[2]), C.c_int(8), C.c_int(hs[i]), C.c_int(ws[j]), C.c_int(H), C.c_int(W),
-                                      C.c_int(y0), C.c_int(x0), stream()))
-                x0 += ws[j]
-            y0 += hs[i]
-        return out
+        s_up = self.downsample_scale
+        Hs, Ws = z.shape[3] * s_up, z.shape[4] * s_up
+        T_out = 1 + (2 ** sum(self.cfg["temporal_up_sample"])) * (z.shape[2] - 1)
+        overlap_px = int(tile_sample_min_size * 0.75)
+        c0, nc, ncols_total = self.tile_cols
+        # pixel extent of this rank's column block in the final frame (each tile contributes `limit` columns, the
+        # last one what is left)
+        x_begin = c0 * overlap_px
+        x_end = min((c0 + nc) * overlap_px, Ws) if (c0 + nc) < ncols_total else Ws
+        if nc == 0:
+            x_begin = x_end = 0
+        Wloc = max(x_end - x_begin, 0)
+        out = torch.empty(T_out, Hs, max(Wloc, 1), 3, dtype=torch.uint8, device=self.dev)
+        if nc:
+            hs = [min(r[0].shape[1], limit) for r in rows]
+            ws = [min(t.shape[2], limit) for t in rows[0]]
+            assert sum(hs) == Hs and sum(ws) == Wloc, (hs, ws, Hs, Wloc)
+            y0 = 0
+            for i, row in enumerate(rows):
+                x0 = 0
+                for j, t in enumerate(row):
+                    check(lib.pf_to_uint8(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int(T_out), C.c_int(t.shape[1]),
+                                          C.c_int(t.shape[2]), C.c_int(8), C.c_int(hs[i]), C.c_int(ws[j]), C.c_int(Hs), C.c_int(Wloc),
+                                          C.c_int(y0), C.c_int(x0), stream()))
+                    x0 += ws[j]
+                y0 += hs[i]
+        if comm is None or comm.world == 1:
+            return out
+        # ---- assemble on rank 0 (column blocks are strided in the final frames: receive, then place)
+        from .sp import even_split, starts_of
+        ncs = even_split(ncols_total, comm.world)
+        c0s = starts_of(ncs)
+        if comm.rank != 0:
+            if nc:
+                comm.send(out, 0)
+            return None
+        full = torch.empty(T_out, Hs, Ws, 3, dtype=torch.uint8, device=self.dev)
+        full[:, :, x_begin:x_end] = out[:, :, :Wloc]
+        for r in range(1, comm.world):
+            if not ncs[r]:
+                continue
+            xb = c0s[r] * overlap_px
+            xe = min((c0s[r] + ncs[r]) * overlap_px, Ws) if (c0s[r] + ncs[r]) < ncols_total else Ws
+            blk = torch.empty(T_out, Hs, xe - xb, 3, dtype=torch.uint8, device=self.dev)
+            comm.recv(blk, r)
+            full[:, :, xb:xe] = blk
+        return full
 
     @torch.no_grad()
     def decode(self, z, is_init_image=True, temporal_chunk=False, return_dict=True, window_size=2, tile_sample_min_size=256):

@@ -52,16 +52,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,heads", [(2, 4), (3, 4), (4, 6)])
-def test_sp_multi_process_exchange(tmp_path, world, heads):
-    """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 6 over 4)."""
+def _launch(world, script, args, tmp_path):
     port = _free_port()
     out = tmp_path / "sp.txt"
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", "sp_worker.py"), str(out), str(heads)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", script), str(out)] + [str(a) for a in args],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -74,3 +72,15 @@ def test_sp_multi_process_exchange(tmp_path, world, heads):
         logs.append(o.decode()[-2000:])
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
     print(out.read_text())
+
+
+@pytest.mark.parametrize("world,heads", [(2, 4), (3, 4), (4, 6)])
+def test_sp_multi_process_exchange(tmp_path, world, heads):
+    """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 6 over 4)."""
+    _launch(world, "sp_worker.py", [heads], tmp_path)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sp_generate_and_tile_parallel_decode(tmp_path, world):
+    """whole generate() (3 stages, 3 units) + tile-parallel VAE decode on `world` ranks == single process, bitwise."""
+    _launch(world, "sp_pipeline_worker.py", [], tmp_path)
