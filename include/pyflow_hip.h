@@ -138,6 +138,12 @@ int pf_cfg_euler_step(const float* v, long long vb_stride, int ld, float* x, int
                       int use_cfg, float dsigma, int round_bf16, pf_stream_t stream);
 int pf_copy_rows(const void* src, void* dst, int rows, int D, int ld_src, int ld_dst, long long src_bstride,
                  long long dst_bstride, int B, pf_stream_t stream);
+/* pf_sp_relayout: pack / unpack of the sequence-parallel all-to-all chunks (replaces the tensor_split + contiguous +
+ *   cat copies of trainer_misc/communicate.py:17-21).  For part p < n_parts (host arrays col0/cols/off, elements):
+ *   chunks[off[p] + (r*B + b)*cols[p] + c]  <->  mat[b*mat_bstride + r*ld + col0[p] + c],  c < cols[p], r < rows.
+ *   to_chunks = 1 packs (mat -> chunks), 0 unpacks. */
+int pf_sp_relayout(void* mat, void* chunks, int rows, int B, int ld, long long mat_bstride, int n_parts,
+                   const int* col0, const int* cols, const long long* off, int to_chunks, pf_stream_t stream);
 /* pf_renoise_upsample: xout = alpha * nearest_up2(xin) + beta * noise   (pipeline.py:729-743) */
 int pf_renoise_upsample(const float* xin, const float* noise, float* xout, int C, int H, int W, float alpha,
                         float beta, int round_bf16, pf_stream_t stream);

@@ -230,6 +230,26 @@ __global__ void copy_rows_kernel(const bf16_t* src, bf16_t* dst, int rows, int D
         *(const u32x4_t*)(src + (long long)b * sbs + (long long)r * lds_ + ch * 8);
 }
 
+// column-block re-layout between a token-major matrix M[b][r][ld] and the per-peer chunks of a sequence-parallel
+// all-to-all:  chunk p = X[off_p + (r*B + b)*cols_p + c]  <->  M[b][r][col0_p + c],  c < cols_p.
+struct SpParts { int n; int col0[16]; int cols[16]; long long off[16]; };
+__global__ void sp_relayout_kernel(bf16_t* mat, bf16_t* chunks, int rows, int B, int ld, long long mat_bstride,
+                                   int total_chunks8, SpParts parts, int to_chunks) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over (r, b, 8-column piece of all parts)
+    const long long total = (long long)rows * B * total_chunks8;
+    if (i >= total) return;
+    int ch = i % total_chunks8;
+    const long long rb = i / total_chunks8;
+    const int b = rb % B;
+    const int r = rb / B;
+    int p = 0;
+    while (ch >= (parts.cols[p] >> 3)) { ch -= parts.cols[p] >> 3; ++p; }
+    bf16_t* m = mat + (long long)b * mat_bstride + (long long)r * ld + parts.col0[p] + ch * 8;
+    bf16_t* x = chunks + parts.off[p] + ((long long)r * B + b) * parts.cols[p] + ch * 8;
+    if (to_chunks) *(u32x4_t*)x = *(const u32x4_t*)m;
+    else *(u32x4_t*)m = *(const u32x4_t*)x;
+}
+
 // x_out[C,H,W] = alpha * nearest_up2(x_in[C,H/2,W/2]) + beta * noise[C,H,W]   (pipeline.py:729-743)
 __global__ void renoise_kernel(const float* xin, const float* noise, float* xout, int C, int H, int W, float alpha,
                                float beta, int round_bf16) {
@@ -355,6 +375,27 @@ extern "C" int pf_copy_rows(const void* src, void* dst, int rows, int D, int ld_
     const long long total = (long long)B * rows * (D / 8);
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)src,
                        (bf16_t*)dst, rows, D, ld_src, ld_dst, src_bstride, dst_bstride, B);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_sp_relayout(void* mat, void* chunks, int rows, int B, int ld, long long mat_bstride, int n_parts,
+                              const int* col0, const int* cols, const long long* off, int to_chunks, hipStream_t stream) {
+    if (!mat || !chunks || !col0 || !cols || !off) return pf_set_err("pf_sp_relayout: null operand");
+    if (n_parts < 1 || n_parts > 16) return pf_set_err("pf_sp_relayout: 1..16 parts");
+    SpParts parts{};
+    parts.n = n_parts;
+    int total8 = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if ((col0[p] % 8) || (cols[p] % 8) || (off[p] % 8)) return pf_set_err("pf_sp_relayout: columns / offsets must be multiples of 8");
+        parts.col0[p] = col0[p]; parts.cols[p] = cols[p]; parts.off[p] = off[p];
+        total8 += cols[p] / 8;
+    }
+    if (ld % 8) return pf_set_err("pf_sp_relayout: ld must be a multiple of 8");
+    const long long total = (long long)rows * B * total8;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(sp_relayout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (bf16_t*)mat,
+                       (bf16_t*)chunks, rows, B, ld, mat_bstride, total8, parts, to_chunks);
     CHECK_LAUNCH();
     return 0;
 }

@@ -40,31 +40,25 @@ class FluxEngineSP(FluxEngine):
         return lay
 
     # ---- the two exchanges -------------------------------------------------------------------------------------
-    def _exchange_qkv(self, lay, big, ld, B, send, recv):
-        """big[B][nloc][ld] (first 3d columns head-major) -> recv[L][B][my_cols]"""
+    def _exchange_qkv(self, lay, big, ld, B, send, recv, async_op=False):
+        """big[B][nloc][ld] (first 3d columns head-major) -> recv[L][B][my_cols]; returns a wait handle or None"""
         nloc = lay.nloc
-        off = 0
-        for p in range(lay.P):
-            cols = lay.heads[p] * lay.HEAD_COLS
-            if cols and nloc:
-                ops.copy_rows(big, send, nloc, cols, ld, B * cols, nloc * ld, cols, B,
-                              src_off=lay.head0[p] * lay.HEAD_COLS, dst_off=off)
-            off += nloc * B * cols
         s_spl, r_spl = lay.a2a1_splits(B)
-        self.comm.all_to_all(recv, send, r_spl, s_spl)
+        if nloc:
+            parts = [p for p in range(lay.P) if lay.heads[p]]
+            ops.sp_relayout(big, send, nloc, B, ld, nloc * ld, [lay.head0[p] * lay.HEAD_COLS for p in parts],
+                            [lay.heads[p] * lay.HEAD_COLS for p in parts], [sum(s_spl[:p]) for p in parts], True)
+        return self.comm.all_to_all(recv, send, r_spl, s_spl, async_op=async_op)
 
     def _exchange_out(self, lay, obuf, B, recv, dst, ld_dst, col0):
         """obuf[L][B][my_heads*64] -> dst[B][nloc][ld_dst] columns col0 .. col0 + d (all heads, head order)"""
         s_spl, r_spl = lay.a2a2_splits(B)
         self.comm.all_to_all(recv, obuf, r_spl, s_spl)
         nloc = lay.nloc
-        off = 0
-        for p in range(lay.P):
-            cols = lay.heads[p] * 64
-            if cols and nloc:
-                ops.copy_rows(recv, dst, nloc, cols, B * cols, ld_dst, cols, nloc * ld_dst, B,
-                              src_off=off, dst_off=col0 + lay.head0[p] * 64)
-            off += nloc * B * cols
+        if nloc:
+            parts = [p for p in range(lay.P) if lay.heads[p]]
+            ops.sp_relayout(dst, recv, nloc, B, ld_dst, nloc * ld_dst, [col0 + lay.head0[p] * 64 for p in parts],
+                            [lay.heads[p] * 64 for p in parts], [sum(r_spl[:p]) for p in parts], False)
 
     # ---- forward ----------------------------------------------------------------------------------------------
     def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):
@@ -112,9 +106,14 @@ class FluxEngineSP(FluxEngine):
             if rows:
                 ops.ln_modulate(hidden, xn, (mod, sh), (mod, sc), d, B, rows, Ld, Ld, d, d, nm, x_off=x_off, y_off=x_off)
 
-        def attend(ld):
-            """big (first 3d columns, head-major) -> attention output for all heads in big[:, :, col0 .. col0+d)"""
-            self._exchange_qkv(lay, big, ld, B, send1, recv1)
+        def attend(ld, overlap=None):
+            """big (first 3d columns, head-major) -> obuf = attention output of my heads for all rows.
+            `overlap`: work that does not depend on the exchange, queued while the all-to-all is in flight."""
+            h = self._exchange_qkv(lay, big, ld, B, send1, recv1, async_op=overlap is not None)
+            if overlap is not None:
+                overlap()
+            if h is not None:
+                h.wait()
             if mh:
                 ops.qk_norm_rope(recv1, B * mc, mc, 128, 0, *norms, plan.rope, B, L, Lt, mh, q_scale=qs,
                                  head_stride=lay.HEAD_COLS)
@@ -162,11 +161,17 @@ class FluxEngineSP(FluxEngine):
         for blk in w.sgl:
             mb = blk["mod"]
             ln(nloc, 0, mb, mb + d)
+            # K|V|Q first, then the MLP branch (proj_mlp + GELU, flux_block.py:921-922) while the qkv all-to-all flies
             if nloc:
-                ops.gemm(xn, blk["kvqm"][0], big, nloc, 7 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, gelu_from=3 * d)
+                ops.gemm(xn, blk["kvqm"][0], big, nloc, 3 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
+                         strideC=L7)
+
+            def mlp_branch(blk=blk):
+                if nloc:
+                    ops.gemm(xn, blk["kvqm"][0], big, nloc, 4 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B,
+                             strideA=Ld, strideC=L7, gelu_from=0, w_off=3 * d * d, c_off=3 * d, bias_off=3 * d)
             norms = (blk["norm_q"], blk["norm_k"], None, None)
-            attend(7 * d)
+            attend(7 * d, overlap=mlp_branch)
             self._exchange_out(lay, obuf, B, recv2, big, 7 * d, 2 * d)      # [attn | mlp] = big[..., 2d:7d)
             if nloc:
                 ops.gemm(big, blk["out"][0], hidden, nloc, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,

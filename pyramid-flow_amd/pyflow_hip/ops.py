@@ -42,7 +42,7 @@ PROFILER = KernelProfiler()
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
-         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0):
+         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0):
     """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res."""
     lib = L.load()
     esz_c = 4 if (flags & GEMM_OUT_F32) else 2
@@ -50,7 +50,7 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.A = A.data_ptr() + 2 * a_off
     d.W = W.data_ptr() + 2 * w_off
     d.C = Cout.data_ptr() + esz_c * c_off
-    d.bias = bias.data_ptr() if bias is not None else None
+    d.bias = (bias.data_ptr() + 4 * bias_off) if bias is not None else None
     d.res = (res.data_ptr() + 2 * r_off) if res is not None else None
     d.gate = (gate.data_ptr() + 4 * gate_off) if gate is not None else None
     d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr = M, N, K, lda, ldw, ldc, ldr
@@ -150,6 +150,15 @@ def copy_rows(src, dst, rows, D, ld_src, ld_dst, src_bstride, dst_bstride, B, ds
     check(lib.pf_copy_rows(C.c_void_p(src.data_ptr() + 2 * src_off), C.c_void_p(dst.data_ptr() + 2 * dst_off),
                            C.c_int(rows), C.c_int(D), C.c_int(ld_src), C.c_int(ld_dst), C.c_longlong(src_bstride),
                            C.c_longlong(dst_bstride), C.c_int(B), stream()))
+
+
+def sp_relayout(mat, chunks, rows, B, ld, mat_bstride, col0, cols, off, to_chunks, mat_off=0):
+    """pack (to_chunks) / unpack the all-to-all chunks; col0 / cols / off: per-part python lists (elements)."""
+    lib = L.load()
+    n = len(cols)
+    check(lib.pf_sp_relayout(C.c_void_p(mat.data_ptr() + 2 * mat_off), ptr(chunks), C.c_int(rows), C.c_int(B), C.c_int(ld),
+                             C.c_longlong(mat_bstride), C.c_int(n), (C.c_int * n)(*col0), (C.c_int * n)(*cols),
+                             (C.c_longlong * n)(*off), C.c_int(int(to_chunks)), stream()))
 
 
 def renoise_upsample(xin, noise, xout, Cc, H, W, alpha, beta, round_bf16):

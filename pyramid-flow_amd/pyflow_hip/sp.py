@@ -67,8 +67,8 @@ class LocalComm:
     """world of one: the exchanges are plain device copies (used to test the SP code path on a single GPU)."""
     rank, world = 0, 1
 
-    def all_to_all(self, recv, send, recv_splits, send_splits):
-        recv[:send.numel()].copy_(send)
+    def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
+        recv[:sum(send_splits)].copy_(send[:sum(send_splits)])
 
     def all_reduce(self, t):
         return t
@@ -101,12 +101,16 @@ class SPComm:
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
-    def all_to_all(self, recv, send, recv_splits, send_splits):
-        """recv / send: flat 1-D tensors; splits in elements, indexed by group rank."""
+    def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
+        """recv / send: flat 1-D tensors; splits in elements, indexed by group rank.
+        async_op (RCCL only): the exchange runs on the communicator's own HIP stream, ordered after the work already
+        queued on the current stream; kernels launched next overlap with it until `.wait()` of the returned handle
+        (which makes the current stream wait, not the host).  Returns None when the exchange completed inline."""
         if self.native:
-            dist.all_to_all_single(recv[:sum(recv_splits)], send[:sum(send_splits)], recv_splits, send_splits,
-                                   group=self.group)
-            return
+            return dist.all_to_all_single(recv[:sum(recv_splits)], send[:sum(send_splits)], recv_splits, send_splits,
+                                          group=self.group, async_op=async_op) if async_op else \
+                dist.all_to_all_single(recv[:sum(recv_splits)], send[:sum(send_splits)], recv_splits, send_splits,
+                                       group=self.group)
         # gloo: no all_to_all; emulate with point-to-point (device tensors staged through the host)
         dev = send.device
         hs = send[:sum(send_splits)].cpu() if dev.type != "cpu" else send
