@@ -165,6 +165,83 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    if constexpr (V == 2) {
+        // ---- variant 2: register-prefetch pipeline, all 8 waves in step.  Fragments of phase p+1 are requested from
+        // LDS before the MFMAs of phase p issue (two fragment sets), B(t+2) / A(t+2) are requested a full K-tile
+        // ahead, ONE barrier per K-tile sits between two MFMA phases (every wave has its next MFMAs' operands in
+        // registers when it is released).
+        constexpr int KS = (BN == 256) ? 1 : 2;      // 16-wide k-steps per phase
+        constexpr int PH = 4 / KS;                   // phases per K-tile
+        bf16x8_t fa[2][2][KS], fb[2][NT][KS];
+        auto loadF = [&](int set, int stg, int bufi, int ph) {
+            const char* sa = sA + stg * A_STAGE + a_row_off;
+            const char* sb = sB + bufi * C_::B_STAGE + b_row_off;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int ch = ((2 * (KS * ph + kk) + fhi) ^ fswz) << 4;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[set][i][kk] = *(const bf16x8_t*)(sa + i * 32 * 128 + ch);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[set][j][kk] = *(const bf16x8_t*)(sb + j * 32 * 128 + ch);
+            }
+        };
+        // MFMAs of fragment set `set`; `between` (next phase's LDS reads / DMA issue / tile hand-over) is placed after
+        // the FIRST MFMA: the compiler's lgkmcnt wait for this set then precedes the new reads (it cannot count
+        // across them), and the reads land under the remaining MFMAs.
+        auto phase = [&](int set, auto&& between) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][0][0], fb[set][0][0], acc[0][0], 0, 0, 0);
+            PF_SCHED_FENCE();
+            between();
+            PF_SCHED_FENCE();
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        if (kk | i | j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][kk], fb[set][j][kk], acc[i][j], 0, 0, 0);
+        };
+        issueA(0, 0);
+        issueB(0, 0);
+        if (nk > 1) {
+            issueA(1, 1);
+            issueB(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PF_BARRIER();
+        loadF(0, 0, 0, 0);
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            const int stage_n = stage == 2 ? 0 : stage + 1;
+#pragma unroll
+            for (int ph = 0; ph < PH; ++ph) {
+                const int cur = ph & 1, nxt = cur ^ 1;
+                phase(cur, [&]() {
+                    if (ph == PH - 1) {
+                        if (more1) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            PF_BARRIER();
+                            if (more2) issueB(kt + 2, buf);
+                            loadF(nxt, stage_n, buf ^ 1, 0);
+                        }
+                    } else {
+                        loadF(nxt, stage, buf, ph + 1);
+                    }
+                    if (ph == 0 && more2) issueA(kt + 2, stage == 0 ? 2 : stage - 1);
+                });
+            }
+            stage = stage_n;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PF_BARRIER();          // every wave is done with the operand tiles before the epilogue strips overwrite them
+    } else {
     // ---- prologue: A(0), B(0), A(1)
     issueA(0, 0);
     issueB(0, 0);
@@ -214,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
             PF_SCHED_FENCE();
         }
         stage = stage == 2 ? 0 : stage + 1;
+    }
     }
     PF_SCHED_FENCE();
 
@@ -331,8 +409,8 @@ int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
 }
 
 int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
-#define PF_L(BN_) (conv ? (variant ? launch<BN_, true, 1>(a, stream) : launch<BN_, true, 0>(a, stream)) \
-                        : (variant ? launch<BN_, false, 1>(a, stream) : launch<BN_, false, 0>(a, stream)))
+#define PF_L(BN_) (conv ? (variant == 2 ? launch<BN_, true, 2>(a, stream) : launch<BN_, true, 1>(a, stream)) \
+                        : (variant == 2 ? launch<BN_, false, 2>(a, stream) : (variant ? launch<BN_, false, 1>(a, stream) : launch<BN_, false, 0>(a, stream))))
     switch (bn) {
         case 128: return PF_L(128);
         case 192: return PF_L(192);
