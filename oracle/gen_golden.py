@@ -74,6 +74,36 @@ def flux_forward_fixture():
                os.path.join(OUT, "flux_tiny_forward.pt"))
 
 
+MMDIT_SEED = 9
+MMDIT_REF_KW = dict(qk_norm="rms_norm", pos_embed_type="sincos", temp_pos_embed_type="rope", use_flash_attn=False,
+                    use_temporal_causal=True, use_t5_mask=True, add_temp_pos_embed=True, interp_condition_pos=True)
+
+
+def mmdit_forward_fixture():
+    """SD3-style variant as the pipeline configures it (pyramid_dit_for_video_gen_pipeline.py:80-87)."""
+    ref = rh.shims.load_reference()
+    cfg = synth.tiny_mmdit_cfg()
+    m = ref.PyramidDiffusionMMDiT(**cfg, **MMDIT_REF_KW).eval()
+    sd = {k: v.to(torch.bfloat16).float() for k, v in synth.mmdit_state_dict(cfg, seed=MMDIT_SEED, std=0.05, lively=True).items()}
+    sd["pos_embed.pos_embed"] = synth.mmdit_state_dict(cfg, seed=MMDIT_SEED)["pos_embed.pos_embed"]      # table stays fp32
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(13)
+    B = 2
+    shapes = [(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)]
+    clips = [torch.randn(B, 16, *s, generator=g).to(torch.bfloat16).float() for s in shapes]
+    enc = torch.randn(B, 16, 32, generator=g).to(torch.bfloat16).float()
+    mask = torch.zeros(B, 16, dtype=torch.long)
+    mask[0, :5] = 1
+    mask[1, :12] = 1
+    pooled = torch.randn(B, 16, generator=g)
+    t = torch.tensor([704.0, 704.0])
+    with torch.no_grad():
+        out = m(sample=[clips], encoder_hidden_states=enc, encoder_attention_mask=mask,
+                pooled_projections=pooled, timestep_ratio=t)[0]
+    torch.save(dict(cfg=cfg, weight_seed=MMDIT_SEED, clips=clips, enc=enc, mask=mask, pooled=pooled, timestep=t, out=out),
+               os.path.join(OUT, "mmdit_tiny_forward.pt"))
+
+
 def vae_fixture():
     vae = build_vae()
     g = torch.Generator().manual_seed(12)
@@ -124,6 +154,7 @@ def scheduler_fixture():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     flux_forward_fixture()
+    mmdit_forward_fixture()
     vae_fixture()
     generate_fixture()
     scheduler_fixture()

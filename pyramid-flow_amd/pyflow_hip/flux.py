@@ -59,8 +59,25 @@ class FluxWeights:
         d = H * hd
         assert d % 128 == 0, "model width must be a multiple of 128"
         self.d, self.H = d, H
-        nd, ns = cfg["num_layers"], cfg["num_single_layers"]
+        # variant: miniFLUX ("pyramid_flux": x_embedder Linear, 3-axis RoPE, double + single blocks) or the SD3-style
+        # MMDiT ("pyramid_mmdit", mmdit_modules/modeling_pyramid_mmdit.py:60-149: PatchEmbed3D conv + sincos table,
+        # temporal RoPE over the whole head, joint blocks only, last block context_pre_only, QK-norm eps 1e-5)
+        self.mmdit = "pos_embed.proj.weight" in sd
+        nd, ns = cfg["num_layers"], (0 if self.mmdit else cfg["num_single_layers"])
+        self.qk_eps = 1e-5 if self.mmdit else 1e-6
+        self.rope_axes = [hd] if self.mmdit else list(cfg["axes_dims_rope"])
         dev = device
+        if self.mmdit:
+            # Conv2d(k=2, s=2) on a frame == Linear over the (c, p1, p2) patch; tokens arrive as (p1, p2, c)
+            wc = sd["pos_embed.proj.weight"]
+            sd["x_embedder.weight"] = wc.permute(0, 2, 3, 1).reshape(wc.shape[0], -1).contiguous()
+            sd["x_embedder.bias"] = sd["pos_embed.proj.bias"]
+            self.pos_table = sd["pos_embed.pos_embed"][0].clone()           # [max*max, d] fp32 (host)
+            self.pos_max = int(round(self.pos_table.shape[0] ** 0.5))
+            added_q, added_k = "norm_add_q", "norm_add_k"
+        else:
+            self.pos_table = None
+            added_q, added_k = "norm_added_q", "norm_added_k"
 
         def W(name):
             return sd[name + ".weight"]
@@ -108,18 +125,22 @@ class FluxWeights:
             p = f"transformer_blocks.{i}."
             mods += [W(p + "norm1.linear"), W(p + "norm1_context.linear")]
             mod_b += [Bv(p + "norm1.linear"), Bv(p + "norm1_context.linear")]
-            blk = dict(mod=off)
-            off += 12 * d
+            # context_pre_only (last MMDiT block, mmdit_block.py:585-599): the text stream only feeds the attention:
+            # AdaLayerNormContinuous (2d: scale, shift) instead of AdaLayerNormZero, no to_add_out, no ff_context
+            pre_only = (p + "attn.to_add_out.weight") not in sd
+            blk = dict(mod=off, pre_only=pre_only)
+            off += (8 if pre_only else 12) * d
             blk["kvq_img"] = kvq(p + "attn.to_k", p + "attn.to_v", p + "attn.to_q")
             blk["kvq_txt"] = kvq(p + "attn.add_k_proj", p + "attn.add_v_proj", p + "attn.add_q_proj")
             blk["o_img"] = (_bf16(W(p + "attn.to_out.0"), dev), _f32(Bv(p + "attn.to_out.0"), dev))
-            blk["o_txt"] = (_bf16(W(p + "attn.to_add_out"), dev), _f32(Bv(p + "attn.to_add_out"), dev))
             blk["ff1_img"] = (_bf16(W(p + "ff.net.0.proj"), dev), _f32(Bv(p + "ff.net.0.proj"), dev))
             blk["ff2_img"] = (_bf16(W(p + "ff.net.2"), dev), _f32(Bv(p + "ff.net.2"), dev))
-            blk["ff1_txt"] = (_bf16(W(p + "ff_context.net.0.proj"), dev), _f32(Bv(p + "ff_context.net.0.proj"), dev))
-            blk["ff2_txt"] = (_bf16(W(p + "ff_context.net.2"), dev), _f32(Bv(p + "ff_context.net.2"), dev))
-            for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
-                blk[nm] = _f32(sd[p + f"attn.{nm}.weight"], dev)
+            if not pre_only:
+                blk["o_txt"] = (_bf16(W(p + "attn.to_add_out"), dev), _f32(Bv(p + "attn.to_add_out"), dev))
+                blk["ff1_txt"] = (_bf16(W(p + "ff_context.net.0.proj"), dev), _f32(Bv(p + "ff_context.net.0.proj"), dev))
+                blk["ff2_txt"] = (_bf16(W(p + "ff_context.net.2"), dev), _f32(Bv(p + "ff_context.net.2"), dev))
+            for nm, key in (("norm_q", "norm_q"), ("norm_k", "norm_k"), ("norm_added_q", added_q), ("norm_added_k", added_k)):
+                blk[nm] = _f32(sd[p + f"attn.{key}.weight"], dev)
             self.dbl.append(blk)
         for j in range(ns):
             p = f"single_transformer_blocks.{j}."
@@ -166,7 +187,30 @@ class FluxEngine:
         return t
 
     def make_plan(self, clip_shapes, enc_mask):
-        return SequencePlan(clip_shapes, enc_mask, self.cfg["axes_dims_rope"], self.dev)
+        plan = SequencePlan(clip_shapes, enc_mask, self.w.rope_axes, self.dev)
+        if self.w.mmdit:
+            plan.pos = self._pos_rows(clip_shapes)
+        return plan
+
+    def _pos_rows(self, clip_shapes):
+        """additive 2-D sincos position rows [L_img, d] bf16 of PatchEmbed3D (mmdit_modules/modeling_embedding.py:
+        269-308, 326-352 with interp_condition_pos): the table window of the CURRENT clip's token grid, bilinearly
+        resized to each lower-resolution history clip's grid, repeated over the clip's frames.  Host arithmetic once
+        per (unit, stage)."""
+        import torch.nn.functional as F
+        w = self.w
+        ms = w.pos_max
+        oh, ow = clip_shapes[-1][1] // 2, clip_shapes[-1][2] // 2
+        top, left = (ms - oh) // 2, (ms - ow) // 2
+        win = w.pos_table.reshape(1, ms, ms, -1)[:, top:top + oh, left:left + ow, :]
+        rows = []
+        for (t, h, wd) in clip_shapes:
+            h2, w2 = h // 2, wd // 2
+            pe = win
+            if (h2, w2) != (oh, ow):
+                pe = F.interpolate(win.permute(0, 3, 1, 2), size=(h2, w2), mode="bilinear").permute(0, 2, 3, 1)
+            rows.append(pe.reshape(1, h2 * w2, -1).expand(t, -1, -1).reshape(t * h2 * w2, -1))
+        return torch.cat(rows, 0).to(self.dev, torch.bfloat16).contiguous()
 
     def encode_context(self, enc):
         """context_embedder (flux:401): enc [B, Lt, C] -> cached bf16 [B, Lt, d]."""
@@ -241,8 +285,13 @@ class FluxEngine:
                 for b in range(B):
                     ops.patchify(cl[b], tok, (b * L_img + row) * w.in_ch, Cc, t, h, wd, w.in_ch, 0, 1)
             row += n
-        ops.gemm(tok, w.x_w, hidden, L_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
-                 strideA=L_img * w.in_ch, strideC=Ld, c_off=Lt * d)
+        if w.mmdit:       # + sincos position rows (same rows for every batch entry: strideR = 0)
+            ops.gemm(tok, w.x_w, hidden, L_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
+                     strideA=L_img * w.in_ch, strideC=Ld, c_off=Lt * d, res=plan.pos, ldr=d, strideR=0,
+                     flags=GEMM_GATE_RES)
+        else:
+            ops.gemm(tok, w.x_w, hidden, L_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
+                     strideA=L_img * w.in_ch, strideC=Ld, c_off=Lt * d)
         if debug is not None:
             debug["hidden0"] = hidden[:B * L * d].view(B, L, d).clone()
 
@@ -251,34 +300,40 @@ class FluxEngine:
 
         for blk in w.dbl:
             mb = blk["mod"]
+            pre_only = blk["pre_only"]
             ln(L_img, Lt * d, mb + 0, mb + d)
-            ln(Lt, 0, mb + 6 * d, mb + 7 * d)
+            if pre_only:          # AdaLayerNormContinuous: (scale, shift) = chunks 0, 1 of the 2d modulation
+                ln(Lt, 0, mb + 7 * d, mb + 6 * d)
+            else:
+                ln(Lt, 0, mb + 6 * d, mb + 7 * d)
             ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
                      strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
             ops.gemm(xn, blk["kvq_txt"][0], big, Lt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
                      strideA=Ld, strideC=L3)
             ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
-                             blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs)
+                             blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
             ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
             ops.gemm(big, blk["o_img"][0], hidden, L_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=Lt * 3 * d + 2 * d, c_off=Lt * d, r_off=Lt * d)
-            ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
-                     gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
-                     flags=GEMM_GATE_RES, a_off=2 * d)
+            if not pre_only:
+                ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
+                         gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
+                         flags=GEMM_GATE_RES, a_off=2 * d)
+                ln(Lt, 0, mb + 9 * d, mb + 10 * d)
             ln(L_img, Lt * d, mb + 3 * d, mb + 4 * d)
-            ln(Lt, 0, mb + 9 * d, mb + 10 * d)
             ops.gemm(xn, blk["ff1_img"][0], big, L_img, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
                      strideA=Ld, strideC=L4, gelu_from=0, a_off=Lt * d, c_off=mlp_base + Lt * 4 * d)
             ops.gemm(big, blk["ff2_img"][0], hidden, L_img, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                      res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                      gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + Lt * 4 * d, c_off=Lt * d, r_off=Lt * d)
-            ops.gemm(xn, blk["ff1_txt"][0], big, Lt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
-                     strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
-            ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
-                     res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
+            if not pre_only:
+                ops.gemm(xn, blk["ff1_txt"][0], big, Lt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
+                         strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
+                ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
+                         res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
             if debug is not None and "hidden_d0" not in debug:
                 debug["hidden_d0"] = hidden[:B * L * d].view(B, L, d).clone()
 

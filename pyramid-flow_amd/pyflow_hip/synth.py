@@ -67,6 +67,85 @@ def flux_param_shapes(cfg):
     return s
 
 
+SD3_MMDIT = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64,
+                 num_attention_heads=24, caption_projection_dim=1536, pooled_projection_dim=2048, pos_embed_max_size=192,
+                 joint_attention_dim=4096)
+
+
+def tiny_mmdit_cfg():
+    return dict(sample_size=32, patch_size=2, in_channels=16, num_layers=3, attention_head_dim=64, num_attention_heads=4,
+                caption_projection_dim=256, pooled_projection_dim=16, pos_embed_max_size=48, joint_attention_dim=32)
+
+
+def mmdit_param_shapes(cfg):
+    """state-dict layout of PyramidDiffusionMMDiT (mmdit_modules/modeling_pyramid_mmdit.py:60-149) incl. the
+    persistent sincos buffer `pos_embed.pos_embed`."""
+    d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    hd = cfg["attention_head_dim"]
+    assert cfg["caption_projection_dim"] == d
+    s = OrderedDict()
+
+    def lin(name, o, i):
+        s[name + ".weight"] = (o, i)
+        s[name + ".bias"] = (o,)
+
+    s["pos_embed.pos_embed"] = (1, cfg["pos_embed_max_size"] ** 2, d)
+    s["pos_embed.proj.weight"] = (d, cfg["in_channels"], cfg["patch_size"], cfg["patch_size"])
+    s["pos_embed.proj.bias"] = (d,)
+    lin("time_text_embed.timestep_embedder.linear_1", d, 256)
+    lin("time_text_embed.timestep_embedder.linear_2", d, d)
+    lin("time_text_embed.text_embedder.linear_1", d, cfg["pooled_projection_dim"])
+    lin("time_text_embed.text_embedder.linear_2", d, d)
+    lin("context_embedder", d, cfg["joint_attention_dim"])
+    n = cfg["num_layers"]
+    for i in range(n):
+        p = f"transformer_blocks.{i}."
+        last = i == n - 1
+        lin(p + "norm1.linear", 6 * d, d)
+        lin(p + "norm1_context.linear", (2 if last else 6) * d, d)
+        s[p + "attn.norm_q.weight"] = (hd,)
+        s[p + "attn.norm_k.weight"] = (hd,)
+        for nme in ("to_q", "to_k", "to_v", "add_k_proj", "add_v_proj", "add_q_proj"):
+            lin(p + "attn." + nme, d, d)
+        s[p + "attn.norm_add_q.weight"] = (hd,)
+        s[p + "attn.norm_add_k.weight"] = (hd,)
+        lin(p + "attn.to_out.0", d, d)
+        if not last:
+            lin(p + "attn.to_add_out", d, d)
+        lin(p + "ff.net.0.proj", 4 * d, d)
+        lin(p + "ff.net.2", d, 4 * d)
+        if not last:
+            lin(p + "ff_context.net.0.proj", 4 * d, d)
+            lin(p + "ff_context.net.2", d, 4 * d)
+    lin("norm_out.linear", 2 * d, d)
+    lin("proj_out", cfg["patch_size"] ** 2 * cfg["in_channels"], d)
+    return s
+
+
+def sincos_2d_table(embed_dim, grid_size, base_size):
+    """the persistent `pos_embed.pos_embed` buffer: get_2d_sincos_pos_embed(embed_dim, grid_size, base_size=...)
+    (mmdit_modules/modeling_embedding.py:23-74) -> [grid*grid, D] fp32; host-side table construction."""
+    import numpy as np
+
+    def one_d(dim, pos):
+        omega = np.arange(dim // 2, dtype=np.float64)
+        omega /= dim / 2.0
+        omega = 1.0 / 10000 ** omega
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    g = np.arange(grid_size, dtype=np.float32) / (grid_size / base_size)
+    grid = np.stack(np.meshgrid(g, g), axis=0).reshape([2, 1, grid_size, grid_size])
+    return torch.from_numpy(np.concatenate([one_d(embed_dim // 2, grid[0]), one_d(embed_dim // 2, grid[1])], axis=1)).float()
+
+
+def mmdit_state_dict(cfg, seed=1234, std=0.02, lively=False):
+    """random weights in the MMDiT key layout with the REAL sincos table in the `pos_embed.pos_embed` buffer"""
+    sd = random_state_dict(mmdit_param_shapes(cfg), seed=seed, std=std, lively=lively)
+    d = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    sd["pos_embed.pos_embed"] = sincos_2d_table(d, cfg["pos_embed_max_size"], cfg["sample_size"] // cfg["patch_size"])[None]
+    return sd
+
+
 def vae_decoder_param_shapes(cfg):
     """decoder + post_quant_conv of CausalVideoVAE (video_vae/modeling_causal_vae.py:137-153)."""
     s = OrderedDict()

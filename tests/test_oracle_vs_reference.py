@@ -105,3 +105,40 @@ def test_block_noise_constants_match_torch():
     d = torch.distributions.MultivariateNormal(torch.zeros(4), cov, validate_args=False).sample()
     torch.manual_seed(3)
     assert torch.equal(d, L @ torch.randn(4)) or torch.allclose(d, torch.randn(4) @ L.T)
+
+
+TINY_MMDIT = dict(sample_size=32, patch_size=2, in_channels=16, num_layers=3, attention_head_dim=64, num_attention_heads=4,
+                  caption_projection_dim=256, pooled_projection_dim=16, pos_embed_max_size=48, joint_attention_dim=32,
+                  qk_norm="rms_norm", pos_embed_type="sincos", temp_pos_embed_type="rope", use_flash_attn=False,
+                  use_temporal_causal=True, use_t5_mask=True, add_temp_pos_embed=True, interp_condition_pos=True)
+
+
+def test_mmdit_oracle_vs_reference(ref):
+    """SD3-style variant as the pipeline builds it (pipeline.py:80-87): sincos abs-pos (cropped / bilinear for the
+    lower-resolution history clips) + temporal RoPE + temporal-causal mask + context_pre_only last block."""
+    from oracle import ref_harness as rh
+    from oracle.mmdit_oracle import mmdit_forward, sincos_2d_table
+    from pyflow_hip import synth
+    m = rh.seed_weights(ref.PyramidDiffusionMMDiT(**TINY_MMDIT).eval(), 77)
+    sd = m.state_dict()
+    # the persistent buffer is the published sincos table
+    tab = sincos_2d_table(256, 48, 32 // 2)
+    assert (sd["pos_embed.pos_embed"][0] - tab).abs().max() < 1e-6
+    # key / shape table of the synthetic-weight generator
+    shapes = synth.mmdit_param_shapes(synth.tiny_mmdit_cfg())
+    assert set(shapes) == set(sd), (set(shapes) ^ set(sd))
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    g = torch.Generator().manual_seed(5)
+    clips = [torch.randn(2, 16, 2, 4, 8, generator=g), torch.randn(2, 16, 1, 8, 16, generator=g),
+             torch.randn(2, 16, 1, 16, 32, generator=g), torch.randn(2, 16, 1, 16, 32, generator=g)]
+    enc = torch.randn(2, 16, 32, generator=g)
+    mask = torch.zeros(2, 16, dtype=torch.long)
+    mask[0, :5] = 1
+    mask[1, :12] = 1
+    pooled = torch.randn(2, 16, generator=g)
+    t = torch.tensor([704.262, 704.262])
+    with torch.no_grad():
+        r = m(sample=[clips], encoder_hidden_states=enc, encoder_attention_mask=mask, pooled_projections=pooled,
+              timestep_ratio=t)[0]
+    o = mmdit_forward(sd, TINY_MMDIT, clips, enc, mask, pooled, t)
+    assert (r - o).abs().max().item() < 2e-5
