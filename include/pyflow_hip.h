@@ -75,6 +75,8 @@ typedef struct {
     long long out_base_off;
     int flags; float out_scale;
     int out_t_shift;         /* added to the output frame index, frames < 0 dropped (is_init_image drop, modeling_resnet.py:726) */
+    int in_sh, in_sw;        /* input stride per output pixel in h / w (0 = 1): CausalDownsample2x of the encoder
+                                (modeling_resnet.py:291-336) reads X[... (h*in_sh+dh) ... (w*in_sw+dw) ...] */
 } pf_conv_desc;
 int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
 
@@ -169,6 +171,10 @@ int pf_softmax_rows(void* S, int ld, int n_valid, int n_cols, int rows, float sc
 int pf_latent_to_nhwc(const float* z, void* y, int C, int T, int H, int W, int t0, int nt, int h0, int w0, int th,
                       int tw, int Cp, int Hp, int Wp, long long fs_out, long long off_out, float a0, float b0,
                       float a1, float b1, pf_stream_t stream);
+/* crop [0:crop_h, 0:crop_w] of a channels-last bf16 tile [T][Ht][Wt][Cp] -> fp32 planar out[c][t][y0+y][x0+x], c < C,
+ * out dims [C][T][H][W] (assembly of the tiled-encode moments, modeling_causal_vae.py:452-466) */
+int pf_nhwc_to_planar_f32(const void* tile, float* out, int T, int Ht, int Wt, int Cp, int C, int crop_h, int crop_w,
+                          int H, int W, int y0, int x0, pf_stream_t stream);
 /* blend_v / blend_h of tiled decode (modeling_causal_vae.py:397-407): tiles [T][H][W][Cp] bf16, b updated in place */
 int pf_blend_tiles(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb, int Cp, int extent, int vertical,
                    pf_stream_t stream);

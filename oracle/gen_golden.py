@@ -104,6 +104,72 @@ def mmdit_forward_fixture():
                os.path.join(OUT, "mmdit_tiny_forward.pt"))
 
 
+ENC_SEED = 6
+
+
+def synth_vae_full_sd():
+    """decoder + encoder synthetic weights (bf16-rounded)"""
+    sd = dict(synth_vae_sd())
+    enc = synth.random_state_dict(synth.vae_encoder_param_shapes(synth.TINY_VAE_ENC), seed=ENC_SEED, std=0.05, lively=True)
+    sd.update({k: v.to(torch.bfloat16).float() for k, v in enc.items()})
+    return sd
+
+
+def build_vae_full():
+    ref = rh.shims.load_reference()
+    v = ref.CausalVideoVAE(**VAE_CFG_REF).eval()
+    v.load_state_dict(synth_vae_full_sd(), strict=True)
+    return v
+
+
+def build_mmdit():
+    ref = rh.shims.load_reference()
+    cfg = synth.tiny_mmdit_cfg()
+    m = ref.PyramidDiffusionMMDiT(**cfg, **MMDIT_REF_KW).eval()
+    sd = {k: v.to(torch.bfloat16).float() for k, v in synth.mmdit_state_dict(cfg, seed=MMDIT_SEED, std=0.05, lively=True).items()}
+    sd["pos_embed.pos_embed"] = synth.mmdit_state_dict(cfg, seed=MMDIT_SEED)["pos_embed.pos_embed"]
+    m.load_state_dict(sd, strict=True)
+    return m, cfg
+
+
+def i2v_fixture():
+    """VAE encode (plain + tiled) of a seeded image and the reference's generate_i2v (MMDiT variant) on it."""
+    import numpy as np
+    from PIL import Image
+    vae = build_vae_full()
+    dit, dcfg = build_mmdit()
+    rng = np.random.RandomState(3)
+    # smooth-ish image: low-res noise upsampled, so the tiled blend regions carry structure
+    base = torch.from_numpy(rng.rand(1, 3, 8, 16).astype("float32"))
+    arr = (torch.nn.functional.interpolate(base, size=(64, 128), mode="bilinear")[0].permute(1, 2, 0) * 255).round().byte().numpy()
+    img = Image.fromarray(arr)
+    x = (torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+    with torch.no_grad():
+        mom = vae.encode(x[None, :, None]).latent_dist.parameters
+        vae.enable_tiling()
+        mom_t = vae.encode(x[None, :, None], tile_sample_min_size=32).latent_dist.parameters
+        vae.disable_tiling()
+    pipe = rh.build_ref_pipeline(dit, vae)
+    pipe.model_name = "pyramid_mmdit"
+    pipe.vae_shift_factor, pipe.vae_scale_factor = 0.1490, 1 / 1.8415
+    rh.patch_block_noise(pipe, rh.NoiseStream(1))
+    torch.manual_seed(321)
+    with torch.no_grad():
+        lat = pipe.generate_i2v(prompt="a cat", input_image=img, temp=3, num_inference_steps=[2, 2, 2], guidance_scale=7.0,
+                                video_guidance_scale=4.0, generator=torch.Generator().manual_seed(0), output_type="latent")
+    torch.manual_seed(321)
+    eps = torch.randn(1, 16, 1, 8, 16)             # the global-RNG draw of latent_dist.sample() inside generate_i2v
+    te = pipe.text_encoder
+    pe, pm, pp = te("a cat, hyper quality, Ultra HD, 8K", None)
+    ne, nm, npool = te(NEG, None)
+    torch.save(dict(dit_cfg=dcfg, dit_weight_seed=MMDIT_SEED, vae_cfg=synth.TINY_VAE, vae_enc_cfg=synth.TINY_VAE_ENC,
+                    vae_weight_seed=VAE_SEED, enc_weight_seed=ENC_SEED, image=torch.from_numpy(arr.copy()),
+                    moments=mom.to(torch.bfloat16), moments_tiled32=mom_t.to(torch.bfloat16), posterior_eps=eps,
+                    prompt_embeds=torch.cat([ne, pe]), prompt_mask=torch.cat([nm, pm]), pooled=torch.cat([npool, pp]),
+                    temp=3, steps=[2, 2, 2], guidance=7.0, video_guidance=4.0, latent_seed=0, noise_seed=1, latents=lat),
+               os.path.join(OUT, "i2v_tiny.pt"))
+
+
 def vae_fixture():
     vae = build_vae()
     g = torch.Generator().manual_seed(12)
@@ -155,6 +221,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     flux_forward_fixture()
     mmdit_forward_fixture()
+    i2v_fixture()
     vae_fixture()
     generate_fixture()
     scheduler_fixture()

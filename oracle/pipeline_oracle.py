@@ -79,10 +79,13 @@ def history_clips(clean, unit_index, n_stages, cfg_dup):
 
 def generate_latents(dit_sd, dit_cfg, prompt_embeds, prompt_mask, pooled, init_latents,
                      block_noise_fn, steps_first, steps_video, guidance_scale, video_guidance_scale,
-                     stages=(1, 2, 4), sched_kwargs=None, record=None):
+                     stages=(1, 2, 4), sched_kwargs=None, record=None, forward_fn=None, image_latent=None):
     """generate() up to ``output_type='latent'``.  prompt_* are already [neg, pos] concatenated.
     init_latents [1,16,temp,H/8,W/8] = randn_tensor output.  block_noise_fn(bs,ch,t,h,w) -> tensor.
-    """
+    forward_fn: flux_forward (default) or mmdit_oracle.mmdit_forward.
+    image_latent [1,16,1,h,w] (already normalised): generate_i2v (:791-1003) -- the image is unit 0, units
+    1..temp-1 are sampled from noise slices 0..temp-2 with the video schedule / video guidance."""
+    forward_fn = forward_fn or flux_forward
     sched = SchedulerOracle(**(sched_kwargs or {"stages": len(stages)}))
     n_st = len(stages)
     cfg_on = guidance_scale > 0
@@ -94,8 +97,8 @@ def generate_latents(dit_sd, dit_cfg, prompt_embeds, prompt_mask, pooled, init_l
         w //= 2
         y = F.interpolate(y, size=(h, w), mode="bilinear") * 2
     lat = y.reshape(b, temp, c, h, w).permute(0, 2, 1, 3, 4)
-    generated = []
-    for u in range(temp):
+    generated = [] if image_latent is None else [image_latent.float()]
+    for u in range(len(generated), temp):
         if u == 0:
             past = [[] for _ in range(n_st)]
             x = lat[:, :, :1]
@@ -103,7 +106,7 @@ def generate_latents(dit_sd, dit_cfg, prompt_embeds, prompt_mask, pooled, init_l
         else:
             clean = pyramid_latent(torch.cat(generated, dim=2), n_st - 1)
             past = history_clips(clean, u, n_st, cfg_on)
-            x = lat[:, :, u:u + 1]
+            x = lat[:, :, u:u + 1] if image_latent is None else lat[:, :, u - 1:u]       # :1185 vs :969
             steps, gs = steps_video, video_guidance_scale
         hh, ww = h, w
         for i_s in range(n_st):                                  # :725-786
@@ -119,8 +122,8 @@ def generate_latents(dit_sd, dit_cfg, prompt_embeds, prompt_mask, pooled, init_l
             for t in sched.timesteps:
                 inp = torch.cat([x] * 2) if cfg_on else x
                 timestep = t.expand(inp.shape[0]).to(inp.dtype)
-                v = flux_forward(dit_sd, dit_cfg, past[i_s] + [inp], prompt_embeds, prompt_mask,
-                                 pooled, timestep)
+                v = forward_fn(dit_sd, dit_cfg, past[i_s] + [inp], prompt_embeds, prompt_mask,
+                               pooled, timestep)
                 if cfg_on:
                     vu, vt = v.chunk(2)
                     v = vu + gs * (vt - vu)

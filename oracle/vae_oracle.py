@@ -136,3 +136,72 @@ def to_uint8_frames(image):
     image = image.mul(127.5).add(127.5).clamp(0, 255).byte()
     b, c, t, h, w = image.shape
     return image.permute(0, 2, 3, 4, 1).reshape(b * t, h, w, c)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# encode side (modeling_causal_vae.py:274-308, 409-466; modeling_enc_dec.py:154-198; modeling_block.py:528-541;
+# modeling_resnet.py:291-336, 458-502) -- un-chunked pass (what generate_i2v uses for its single frame)
+def causal_conv3d_strided(sd, name, x, stride=(1, 1, 1)):
+    # causal_conv.py:116-146 with a (t, h, w) stride: pad 2 zero frames in front + 1 px each side, then strided Conv3d
+    w = sd[name + ".conv.weight"]
+    b = sd.get(name + ".conv.bias")
+    kt, kh, kw = w.shape[2:]
+    x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0))
+    return F.conv3d(x, w, b, stride=stride)
+
+
+def encoder_forward(sd, cfg, x):
+    """CausalVaeEncoder.forward + quant_conv on a full clip [B,3,T,H,W] -> moments [B,2*latent,T',H/8,W/8]"""
+    x = causal_conv3d(sd, "encoder.conv_in", x)
+    boc = cfg["encoder_block_out_channels"]
+    for i in range(len(boc)):
+        p = f"encoder.down_blocks.{i}."
+        for j in range(cfg["encoder_layers_per_block"][i]):
+            x = resnet(sd, p + f"resnets.{j}.", x)
+        if cfg["encoder_spatial_down_sample"][i]:
+            x = causal_conv3d_strided(sd, p + "downsamplers.0.conv", x, (1, 2, 2))
+        if cfg["encoder_temporal_down_sample"][i]:
+            x = causal_conv3d_strided(sd, p + "temporal_downsamplers.0.conv", x, (2, 1, 1))
+    x = resnet(sd, "encoder.mid_block.resnets.0.", x)
+    x = mid_attention(sd, "encoder.mid_block.attentions.0.", x)
+    x = resnet(sd, "encoder.mid_block.resnets.1.", x)
+    x = F.silu(group_norm_per_frame(sd, "encoder.conv_norm_out", x))
+    x = causal_conv3d(sd, "encoder.conv_out", x)
+    return causal_conv3d(sd, "quant_conv", x)
+
+
+def vae_encode_moments(sd, cfg, x, use_tiling=False, tile_sample_min_size=256):
+    """CausalVideoVAE.encode up to the posterior parameters (causal_vae.py:274-308, tiled_encode :409-466).
+    x [B,3,T,H,W] in [-1,1] -> moments [B,2*latent,T',h,w]; mean = first half, logvar = second half."""
+    sd = {k: v.float() for k, v in sd.items()}
+    x = x.float()
+    ts = tile_sample_min_size
+    tl = int(ts / 8)
+    if not (use_tiling and (x.shape[-1] > ts or x.shape[-2] > ts)):
+        return encoder_forward(sd, cfg, x)
+    overlap = int(ts * 0.75)
+    blend = int(tl * 0.25)
+    limit = tl - blend
+    rows = []
+    for i in range(0, x.shape[3], overlap):
+        rows.append([encoder_forward(sd, cfg, x[:, :, :, i:i + ts, j:j + ts]) for j in range(0, x.shape[4], overlap)])
+    out_rows = []
+    for i, row in enumerate(rows):
+        res = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = _blend_v(rows[i - 1][j], tile, blend)
+            if j > 0:
+                tile = _blend_h(row[j - 1], tile, blend)
+            res.append(tile[:, :, :, :limit, :limit])
+        out_rows.append(torch.cat(res, dim=4))
+    return torch.cat(out_rows, dim=3)
+
+
+def posterior_sample(moments, eps=None):
+    """DiagonalGaussianDistribution (modeling_enc_dec.py:369-391): mean + exp(0.5*clamp(logvar,-30,20)) * eps;
+    eps None -> mode()."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    if eps is None:
+        return mean
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * eps

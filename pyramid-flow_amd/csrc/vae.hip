@@ -221,6 +221,19 @@ __global__ void blend_kernel(const bf16_t* a, bf16_t* b, int T, int Ha, int Wa, 
     b[ib] = (bf16_t)(av + bv);
 }
 
+__global__ void nhwc_to_planar_kernel(const bf16_t* tile, float* out, int T, int Ht, int Wt, int Cp, int C, int ch, int cw,
+                                      int H, int W, int y0, int x0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)T * ch * cw * C;
+    if (i >= total) return;
+    const int c = i % C;
+    long long r = i / C;
+    const int x = r % cw; r /= cw;
+    const int y = r % ch;
+    const int t = r / ch;
+    out[(((long long)c * T + t) * H + (y0 + y)) * W + (x0 + x)] = (float)tile[(((long long)t * Ht + y) * Wt + x) * Cp + c];
+}
+
 __global__ void to_uint8_kernel(const bf16_t* tile, unsigned char* out, int T, int Ht, int Wt, int Cp, int ch, int cw, int H,
                                 int W, int y0, int x0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,6 +329,17 @@ extern "C" int pf_blend_tiles(const void* a, void* b, int T, int Ha, int Wa, int
     if (total <= 0) return 0;
     hipLaunchKernelGGL(blend_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)a, (bf16_t*)b,
                        T, Ha, Wa, Hb, Wb, Cp, e, vertical);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_nhwc_to_planar_f32(const void* tile, float* out, int T, int Ht, int Wt, int Cp, int C, int crop_h,
+                                     int crop_w, int H, int W, int y0, int x0, hipStream_t stream) {
+    if (!tile || !out) return pf_set_err("pf_nhwc_to_planar_f32: null operand");
+    const long long total = (long long)T * crop_h * crop_w * C;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(nhwc_to_planar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t*)tile, out, T, Ht, Wt, Cp, C, crop_h, crop_w, H, W, y0, x0);
     CHECK_LAUNCH();
     return 0;
 }

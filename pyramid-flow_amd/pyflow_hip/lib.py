@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ("st", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("Cg", C.c_int), ("Hop", C.c_int),
                 ("Wop", C.c_int), ("Cout_pitch", C.c_int),
                 ("out_base_off", C.c_longlong),
-                ("flags", C.c_int), ("out_scale", C.c_float), ("out_t_shift", C.c_int)]
+                ("flags", C.c_int), ("out_scale", C.c_float), ("out_t_shift", C.c_int),
+                ("in_sh", C.c_int), ("in_sw", C.c_int)]
 
 
 class AttnDesc(C.Structure):
@@ -54,7 +55,7 @@ EXPORTS = [
     "pf_last_error", "pf_version", "pf_gemm_bf16", "pf_gemm_set_policy", "pf_conv3d_bf16", "pf_attention_bf16", "pf_v_transpose",
     "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
     "pf_copy_rows", "pf_sp_relayout", "pf_renoise_upsample", "pf_avgpool2",
-    "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_to_uint8",
+    "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",
 ]
 
 

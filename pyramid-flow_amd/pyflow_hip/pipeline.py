@@ -51,9 +51,9 @@ class PyramidDiTForVideoGeneration:
                  interp_condition_pos=True, stages=[1, 2, 4], video_sync_group=8, gradient_checkpointing_ratio=0.6,
                  dit_state_dict=None, dit_config=None, vae_state_dict=None, vae_config=None, text_encoder=None,
                  device="cuda", **kwargs):
-        if model_name != "pyramid_flux":
-            raise NotImplementedError("round 1 implements the miniFLUX (pyramid_flux) variant; pyramid_mmdit is the next "
-                                      "row of the scope table")
+        if model_name not in ("pyramid_flux", "pyramid_mmdit"):
+            raise NotImplementedError("Unsupported DiT architecture, please set the model_name to `pyramid_flux` or "
+                                      "`pyramid_mmdit`")                                     # pipeline.py:88-89
         assert use_temporal_causal and interp_condition_pos and not use_flash_attn
         assert frame_per_unit == 1, "fixed unit implementation (pipeline.py:181-186)"
         self.stages = list(stages)
@@ -83,7 +83,10 @@ class PyramidDiTForVideoGeneration:
                 vae_state_dict, vae_config = _load_diffusers_dir(os.path.join(model_path, "causal_video_vae"))
             if vae_state_dict is not None:
                 self.vae = CausalVideoVAE(vae_state_dict, vae_config, device)
-        self.vae_shift_factor, self.vae_scale_factor = -0.04, 1 / 1.8726            # :165-167
+        if model_name == "pyramid_flux":
+            self.vae_shift_factor, self.vae_scale_factor = -0.04, 1 / 1.8726        # :165-167
+        else:
+            self.vae_shift_factor, self.vae_scale_factor = 0.1490, 1 / 1.8415       # :168-170
         self.vae_video_shift_factor, self.vae_video_scale_factor = -0.2343, 1 / 3.0986
         self.downsample = 8
         self.frame_per_unit = frame_per_unit
@@ -306,8 +309,83 @@ class PyramidDiTForVideoGeneration:
         from PIL import Image
         return [Image.fromarray(a) for a in arr]
 
-    def generate_i2v(self, *a, **k):
-        raise NotImplementedError("generate_i2v needs the VAE encoder (scope table row V-4, config C4): next round")
+    @torch.no_grad()
+    def generate_i2v(self, prompt="", input_image=None, temp=1, num_inference_steps=28, guidance_scale=7.0,
+                     video_guidance_scale=4.0, min_guidance_scale=2.0, use_linear_guidance=False, alpha=0.5,
+                     negative_prompt=DEFAULT_NEGATIVE, num_images_per_prompt=1, generator=None, output_type="pil",
+                     save_memory=True, cpu_offloading=False, inference_multigpu=False, callback=None,
+                     prompt_embeds=None, posterior_noise=None):
+        """:791-1003.  input_image: PIL.Image (as the reference) or a float tensor [3,H,W] already in [-1,1].
+        `posterior_noise` ([1,C,1,h,w]) replaces the global-RNG draw of latent_dist.sample() (:911) for
+        reproducible comparisons; `prompt_embeds` as in generate()."""
+        if self.vae is None or not self.vae.has_encoder:
+            raise RuntimeError("generate_i2v needs a VAE with encoder weights")
+        if isinstance(input_image, torch.Tensor):
+            img = input_image.float()
+        else:       # transforms.ToTensor + Normalize(0.5, 0.5) of :906-909
+            arr = torch.from_numpy(np.asarray(input_image.convert("RGB"), dtype=np.uint8).copy())
+            img = (arr.permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+        height, width = img.shape[-2], img.shape[-1]
+        assert temp % self.frame_per_unit == 0, "The frames should be divided by frame_per unit"
+        assert height % 64 == 0 and width % 64 == 0, "height/width must be multiples of 64 (8 VAE x 4 pyramid x 2 patch)"
+        n_st = len(self.stages)
+        if isinstance(num_inference_steps, int):
+            num_inference_steps = [num_inference_steps] * n_st
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise RuntimeError("no text encoder loaded: pass prompt_embeds=(...) (synthetic prompts) or a text_encoder")
+            prompt = prompt + ", hyper quality, Ultra HD, 8K" if isinstance(prompt, str) else \
+                [p_ + ", hyper quality, Ultra HD, 8K" for p_ in prompt]
+            pe, pm, pp = self.text_encoder(prompt, self._device)
+            ne, nm, npool = self.text_encoder(negative_prompt or "", self._device)
+        else:
+            pe, pm, pp, ne, nm, npool = prompt_embeds
+        self._guidance_scale = guidance_scale
+        self._video_guidance_scale = video_guidance_scale
+        if use_linear_guidance:
+            guidance_scale_list = [max(guidance_scale - alpha * t_, min_guidance_scale) for t_ in range(temp + 1)]
+        if self.do_classifier_free_guidance:
+            pe = torch.cat([ne, pe], dim=0)
+            pp = torch.cat([npool, pp], dim=0)
+            pm = torch.cat([nm, pm], dim=0)
+        self._round = (self.model_dtype == "bf16") and pe.dtype == torch.bfloat16
+        self.dit.encode_context(pe)
+        C = self.dit.w.out_cols // 4
+        latents = self.prepare_latents(1, C, temp, height, width, pe.dtype, self._device, generator)
+        x = latents[0].to(self._device, torch.float32).contiguous()
+        if self.sp is not None:
+            self.sp.broadcast(x, 0)
+        for _ in range(n_st - 1):
+            Cc, T, H, W = x.shape
+            y = torch.empty(Cc, T, H // 2, W // 2, dtype=torch.float32, device=self._device)
+            ops.avgpool2(x, y, Cc * T, H, W, 2.0, self._round)
+            x = y
+        # image latent (:906-911): encode, sample the posterior, normalise with the IMAGE statistics
+        post = self.vae.encode(img[None, :, None].to(self._device)).latent_dist
+        z = post.sample(eps=posterior_noise) if posterior_noise is not None else post.sample()
+        z = ((z - self.vae_shift_factor) * self.vae_scale_factor)[0].float().contiguous()        # [C,1,h,w]
+        if self._round:
+            z = z.to(torch.bfloat16).float()
+        if self.sp is not None:
+            self.sp.broadcast(z, 0)                                                           # :913-917
+        num_units = temp // self.frame_per_unit
+        generated = [z]
+        for unit_index in range(1, num_units):
+            if callback:
+                callback(unit_index, num_units)
+            if use_linear_guidance:
+                self._guidance_scale = guidance_scale_list[unit_index]
+                self._video_guidance_scale = guidance_scale_list[unit_index]
+            clean = self._pyramid(torch.cat(generated, dim=1), n_st - 1)
+            past = self._history(clean, unit_index)
+            outs = self.generate_one_unit(x[:, unit_index - 1:unit_index].contiguous(), past, pm, pp,
+                                          num_inference_steps, False)
+            generated.append(outs[-1])
+        gen = torch.cat(generated, dim=1)[None]
+        if output_type == "latent":
+            return gen.to(pe.dtype) if self._round else gen
+        return self.decode_latent(gen, save_memory=save_memory, inference_multigpu=inference_multigpu,
+                                  output_type=output_type)
 
 
 def _load_diffusers_dir(path):

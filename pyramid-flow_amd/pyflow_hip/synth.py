@@ -194,6 +194,60 @@ def vae_decoder_param_shapes(cfg):
     return s
 
 
+def vae_encoder_param_shapes(cfg):
+    """encoder + quant_conv of CausalVideoVAE (video_vae/modeling_causal_vae.py:120-136, modeling_enc_dec.py:55-152);
+    cfg: latent_channels, encoder_block_out_channels, encoder_layers_per_block, encoder_spatial/temporal_down_sample."""
+    s = OrderedDict()
+    boc = cfg["encoder_block_out_channels"]
+    lat = cfg["latent_channels"]
+
+    def conv(name, co, ci, k):
+        s[name + ".conv.weight"] = (co, ci, k, k, k)
+        s[name + ".conv.bias"] = (co,)
+
+    def norm(name, c):
+        s[name + ".weight"] = (c,)
+        s[name + ".bias"] = (c,)
+
+    def resnet(p, ci, co):
+        norm(p + "norm1", ci)
+        conv(p + "conv1", co, ci, 3)
+        norm(p + "norm2", co)
+        conv(p + "conv2", co, co, 3)
+        if ci != co:
+            conv(p + "conv_shortcut", co, ci, 1)
+
+    conv("encoder.conv_in", boc[0], 3, 3)
+    prev = boc[0]
+    for i, co in enumerate(boc):
+        p = f"encoder.down_blocks.{i}."
+        for j in range(cfg["encoder_layers_per_block"][i]):
+            resnet(p + f"resnets.{j}.", prev if j == 0 else co, co)
+        if cfg["encoder_spatial_down_sample"][i]:
+            conv(p + "downsamplers.0.conv", co, co, 3)
+        if cfg["encoder_temporal_down_sample"][i]:
+            conv(p + "temporal_downsamplers.0.conv", co, co, 3)
+        prev = co
+    top = boc[-1]
+    resnet("encoder.mid_block.resnets.0.", top, top)
+    a = "encoder.mid_block.attentions.0."
+    norm(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[a + n + ".weight"] = (top, top)
+        s[a + n + ".bias"] = (top,)
+    resnet("encoder.mid_block.resnets.1.", top, top)
+    norm("encoder.conv_norm_out", top)
+    conv("encoder.conv_out", 2 * lat, top, 3)
+    conv("quant_conv", 2 * lat, 2 * lat, 1)
+    return s
+
+
+TINY_VAE_ENC = dict(latent_channels=16, encoder_block_out_channels=(32, 32, 64, 64), encoder_layers_per_block=(1, 1, 1, 1),
+                    encoder_spatial_down_sample=(True, True, True, False), encoder_temporal_down_sample=(True, True, True, False))
+VAE_ENC_DEFAULT = dict(latent_channels=16, encoder_block_out_channels=(128, 256, 512, 512), encoder_layers_per_block=(2, 2, 2, 2),
+                       encoder_spatial_down_sample=(True, True, True, False), encoder_temporal_down_sample=(True, True, True, False))
+
+
 def random_state_dict(shapes, seed=1234, std=0.02, lively=False, dtype=torch.float32):
     """N(0, std^2) matrices, norm gains 1, biases 0.  lively=True perturbs gains and
     biases too (tests: exercises every term)."""

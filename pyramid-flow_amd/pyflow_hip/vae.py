@@ -75,21 +75,23 @@ class ConvW:
         self.N, self.n_valid, self.Cg, self.groups, self.cin_p = Np, n_valid, cg, groups, cp
 
 
-def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None):
-    """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple."""
+def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1):
+    """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple.
+    down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2."""
     lib = L.load()
     d = ConvDesc()
     d.X = src.t.data_ptr()
     d.W = cw.w.data_ptr()
     d.bias = cw.b.data_ptr()
-    d.T, d.H, d.W_ = Tc, src.H, src.W
+    d.T, d.H, d.W_ = Tc, src.H // down, src.W // down
+    d.in_sh = d.in_sw = down
     d.Hp, d.Wp, d.Cin = src.Hp, src.Wp, src.Cp
     d.kt, d.kh, d.kw = cw.kt, cw.kh, cw.kw
     assert cw.cin_p == src.Cp
-    if cw.kt == 3:
-        d.in_base_off = 0
-    else:
-        d.in_base_off = src.off(2)
+    # first temporal slot the taps touch (kt = 3: the two cache slots + the frame; kt = 1: the frame itself) and, for
+    # spatial taps, the padded origin (row -1, col -1) instead of the first interior pixel
+    slot0 = 2 - (cw.kt - 1)
+    d.in_base_off = slot0 * src.fs + ((src.Wp + 1) * src.Cp if cw.kh == 1 else 0)
     d.N, d.n_valid = cw.N, cw.n_valid
     d.st, d.sh, d.sw, d.Cg = st, sh, sw, cw.Cg
     if dst_raw is not None:
@@ -103,14 +105,14 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None):
         d.Y = dst.t.data_ptr()
         d.Hop, d.Wop, d.Cout_pitch = dst.Hp, dst.Wp, dst.Cp
         d.out_base_off = dst.off(2)
-        assert dst.H == src.H * sh and dst.W == src.W * sw
+        assert dst.H == src.H * sh // down and dst.W == src.W * sw // down
     d.flags = GEMM_GATE_RES if res is not None else 0
     d.res = res.t.data_ptr() if res is not None else None
     if res is not None:
         assert (res.Hp, res.Wp, res.Cp) == (dst.Hp, dst.Wp, dst.Cp)
     d.out_scale = 1.0
     d.out_t_shift = t_shift
-    ops.PROFILER.launch("conv3d", 2.0 * Tc * src.H * src.W * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
+    ops.PROFILER.launch("conv3d", 2.0 * Tc * (src.H // down) * (src.W // down) * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
                         lambda: check(lib.pf_conv3d_bf16(C.byref(d), stream())))
     if dst is not None:
         dst.cur = Tc * st + t_shift
@@ -119,7 +121,7 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None):
 class _TileProgram:
     """all buffers + the layer sequence for one latent tile geometry (th x tw)."""
 
-    def __init__(self, vae, th, tw, t_first, t_later):
+    def __init__(self, vae, th, tw, t_first, t_later, encoder=False):
         self.vae, self.th, self.tw = vae, th, tw
         self.bufs = {}
         self.dev = vae.dev
@@ -127,7 +129,7 @@ class _TileProgram:
         # frames per chunk at each temporal level (first chunk / later chunks)
         self.tmax = [max(t_first, t_later)]
         tf_, tl = t_first, t_later
-        for up in cfg["temporal_up_sample"]:
+        for up in ([] if encoder else cfg["temporal_up_sample"]):
             if up:
                 tf_, tl = 2 * tf_ - 1, 2 * tl
                 self.tmax.append(max(tf_, tl))
@@ -197,15 +199,16 @@ class _TileProgram:
         n2.shift_cache()
         return out
 
-    def mid_attention(self, x, out_name):
+    def mid_attention(self, x, out_name, side="decoder"):
         """per-frame 1-head attention (modeling_block.py:456-460 + diffusers Attention, deprecated-attn-block form)."""
         v = self.vae
         Tc, n, npad, ca = x.cur, self.n_tok, self.npad, v.attn_pitch
-        self.gn(x, None, "decoder.mid_block.attentions.0.group_norm", silu=False, dst_raw=(self.a_x, ca))
-        wq, bq = v.attn["to_q"]
-        wk, bk = v.attn["to_k"]
-        wv, bv = v.attn["to_v"]
-        wo, bo = v.attn["to_out.0"]
+        self.gn(x, None, side + ".mid_block.attentions.0.group_norm", silu=False, dst_raw=(self.a_x, ca))
+        attn = v.attn if side == "decoder" else v.enc_attn
+        wq, bq = attn["to_q"]
+        wk, bk = attn["to_k"]
+        wv, bv = attn["to_v"]
+        wo, bo = attn["to_out.0"]
         ops.gemm(self.a_x, wq, self.a_q, npad, ca, ca, ca, ca, ca, bias=bq, batch=Tc, strideA=npad * ca, strideC=npad * ca)
         ops.gemm(self.a_x, wk, self.a_k, npad, ca, ca, ca, ca, ca, bias=bk, batch=Tc, strideA=npad * ca, strideC=npad * ca)
         out = self.buf(out_name, 0, x.H, x.W, x.C)
@@ -288,6 +291,73 @@ class _TileProgram:
         return nf
 
 
+    # ---- one FRAME through encoder + quant_conv (modeling_enc_dec.py:154-198) ---------------------------------------
+    def run_encoder_frame(self, img, h0, w0, out_tile):
+        """img [3,1,H,W] fp32 in [-1,1]; the window (h0, w0, 8*th, 8*tw) -> moments tile [1][th][tw][64] bf16.
+        A single frame sees two zero frames in front of every causal conv (modeling_causal_conv.py:116-146), so each
+        3x3x3 filter reduces to its last temporal tap: the filters are packed as kt = 1 (CausalVideoVAE.__init__)."""
+        v = self.vae
+        ecfg = v.enc_cfg
+        s_ = 2 ** sum(ecfg["spatial_down_sample"])
+        ph, pw = self.th * s_, self.tw * s_
+        xin = self.buf("e.img", 0, ph, pw, 3)
+        lib = L.load()
+        Zc, ZT, ZH, ZW = img.shape
+        check(lib.pf_latent_to_nhwc(C.c_void_p(img.data_ptr()), C.c_void_p(xin.t.data_ptr()), C.c_int(Zc), C.c_int(ZT),
+                                    C.c_int(ZH), C.c_int(ZW), C.c_int(0), C.c_int(1), C.c_int(h0), C.c_int(w0),
+                                    C.c_int(ph), C.c_int(pw), C.c_int(xin.Cp), C.c_int(xin.Hp), C.c_int(xin.Wp),
+                                    C.c_longlong(xin.fs), C.c_longlong(xin.off(2)), C.c_float(1.0), C.c_float(0.0),
+                                    C.c_float(1.0), C.c_float(0.0), stream()))
+        xin.cur = 1
+        boc = ecfg["block_out_channels"]
+        x = self.buf("e.conv_in", 0, ph, pw, boc[0])
+        conv(xin, x, v.convs["encoder.conv_in"], 1)
+        for i, co in enumerate(boc):
+            p = f"encoder.down_blocks.{i}."
+            for j in range(ecfg["layers_per_block"][i]):
+                x = self.resnet(x, p + f"resnets.{j}.", 0, f"e.d{i}.r{j}", co)
+            if ecfg["spatial_down_sample"][i]:
+                y = self.buf(f"e.d{i}.sp", 0, x.H // 2, x.W // 2, co)
+                conv(x, y, v.convs[p + "downsamplers.0.conv"], 1, down=2)
+                x = y
+            if ecfg["temporal_down_sample"][i]:        # T = 1: stride-2 temporal conv of [0, 0, x] -> one frame
+                y = self.buf(f"e.d{i}.tp", 0, x.H, x.W, co)
+                conv(x, y, v.convs[p + "temporal_downsamplers.0.conv"], 1)
+                x = y
+        x = self.resnet(x, "encoder.mid_block.resnets.0.", 0, "e.mid.r0", boc[-1])
+        x = self.mid_attention(x, "e.mid.attn", side="encoder")
+        x = self.resnet(x, "encoder.mid_block.resnets.1.", 0, "e.mid.r1", boc[-1])
+        n = self.buf("e.norm_out", 0, x.H, x.W, x.C)
+        self.gn(x, n, "encoder.conv_norm_out")
+        m = self.buf("e.moments", 0, x.H, x.W, 2 * ecfg["latent_channels"])
+        conv(n, m, v.convs["encoder.conv_out"], 1)
+        conv(m, None, v.convs["quant_conv"], 1, dst_raw=(out_tile, x.H, x.W, out_tile.shape[-1], 0))
+
+
+class DiagonalGaussianDistribution:
+    """modeling_enc_dec.py:369-421 (the members the sampling path uses)."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None, eps=None):
+        if eps is None:
+            eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device if generator is None
+                              else generator.device, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * eps.to(self.mean.device, self.mean.dtype)
+
+    def mode(self):
+        return self.mean
+
+
+class EncoderOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+
 class DecoderOutput:
     def __init__(self, sample):
         self.sample = sample
@@ -300,6 +370,7 @@ class CausalVideoVAE:
     def __init__(self, state_dict, cfg=None, device="cuda"):
         from . import synth
         self.dev = torch.device(device)
+        cfg_in = dict(cfg) if cfg else None
         cfg = dict(cfg or synth.VAE_DEFAULT)
         if "decoder_block_out_channels" in cfg:      # reference-style config (causal_vae.py:73-116)
             cfg = dict(latent_channels=cfg.get("decoder_in_channels", 4),
@@ -314,26 +385,41 @@ class CausalVideoVAE:
         self.use_tiling = False
         self.downsample_scale = 8
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()
-              if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
-        self.convs, self.norms, self.attn = {}, {}, {}
+              if k.startswith(("decoder.", "post_quant_conv.", "encoder.", "quant_conv."))}
+        self.has_encoder = any(k.startswith("encoder.") for k in sd)
+        if self.has_encoder:
+            ref_cfg = dict(cfg_in or {})
+            boc = tuple(ref_cfg.get("encoder_block_out_channels", (128, 256, 512, 512)))
+            self.enc_cfg = dict(latent_channels=sd["quant_conv.conv.weight"].shape[0] // 2, block_out_channels=boc,
+                                layers_per_block=tuple(ref_cfg.get("encoder_layers_per_block", (2,) * len(boc))),
+                                spatial_down_sample=tuple(ref_cfg.get("encoder_spatial_down_sample", (True, True, True, False))),
+                                temporal_down_sample=tuple(ref_cfg.get("encoder_temporal_down_sample", (True, True, True, False))))
+        self.convs, self.norms, self.attn, self.enc_attn = {}, {}, {}, {}
         for k in sd:
             if k.endswith(".conv.weight"):
                 name = k[:-len(".conv.weight")]
                 groups = 4 if ".upsamplers." in name else (2 if ".temporal_upsamplers." in name else 1)
-                self.convs[name] = ConvW(sd[k], sd[name + ".conv.bias"], self.dev, groups)
+                wt = sd[k]
+                if name.startswith(("encoder.", "quant_conv")) and wt.shape[2] == 3:
+                    wt = wt[:, :, 2:3]          # single-frame encode: only the last temporal tap meets data
+                self.convs[name] = ConvW(wt, sd[name + ".conv.bias"], self.dev, groups)
             elif k.endswith(".weight") and sd[k].ndim == 1:
                 name = k[:-len(".weight")]
                 self.norms[name] = (sd[k].to(self.dev), sd[name + ".bias"].to(self.dev))
         top = cfg["block_out_channels"][-1]
         self.attn_pitch = ca = _ru(top, 128)
         self.attn_scale = top ** -0.5
-        a = "decoder.mid_block.attentions.0."
-        for n in ("to_q", "to_k", "to_v", "to_out.0"):
-            w = torch.zeros(ca, ca)
-            w[:top, :top] = sd[a + n + ".weight"]
-            b = torch.zeros(ca)
-            b[:top] = sd[a + n + ".bias"]
-            self.attn[n] = (w.to(self.dev, torch.bfloat16).contiguous(), b.to(self.dev))
+        for side, store in (("decoder", self.attn), ("encoder", self.enc_attn)):
+            a = side + ".mid_block.attentions.0."
+            if (a + "to_q.weight") not in sd:
+                continue
+            assert sd[a + "to_q.weight"].shape[0] == top, "encoder / decoder mid blocks share the attention width"
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                w = torch.zeros(ca, ca)
+                w[:top, :top] = sd[a + n + ".weight"]
+                b = torch.zeros(ca)
+                b[:top] = sd[a + n + ".bias"]
+                store[n] = (w.to(self.dev, torch.bfloat16).contiguous(), b.to(self.dev))
         self._programs = {}
 
     def enable_tiling(self, use_tiling=True):
@@ -382,13 +468,13 @@ class CausalVideoVAE:
         assert fo == T_out, (fo, T_out)
         return out
 
-    def _blend(self, a, b, blend, vertical, a_w=None):
+    def _blend(self, a, b, blend, vertical, a_w=None, cp=8):
         """blend_v / blend_h (:397-407): b updated in place from the bottom rows / right columns of a."""
         lib = L.load()
         Tt, Hb, Wb, _ = b.shape
         check(lib.pf_blend_tiles(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_int(Tt),
                                  C.c_int(a.shape[1]), C.c_int(a.shape[2] if a_w is None else a_w), C.c_int(Hb), C.c_int(Wb),
-                                 C.c_int(8), C.c_int(blend), C.c_int(int(vertical)), stream()))
+                                 C.c_int(cp), C.c_int(blend), C.c_int(int(vertical)), stream()))
 
     @torch.no_grad()
     def decode_tiles(self, z, temporal_chunk, window_size, tile_sample_min_size, affine=(1.0, 0.0, 1.0, 0.0), comm=None):
@@ -504,6 +590,75 @@ class CausalVideoVAE:
             comm.recv(blk, r)
             full[:, :, xb:xe] = blk
         return full
+
+    @torch.no_grad()
+    def encode(self, x, return_dict=True, is_init_image=True, temporal_chunk=False, window_size=16, tile_sample_min_size=256):
+        """modeling_causal_vae.py:274-308 / tiled_encode :409-466 for ONE frame (what generate_i2v encodes,
+        pyramid_dit_for_video_gen_pipeline.py:906-911): x [1,3,1,H,W] in [-1,1] -> latent_dist over [1,C,1,H/8,W/8].
+        Multi-frame (chunked) video encode is the next scope row."""
+        if not self.has_encoder:
+            raise RuntimeError("this CausalVideoVAE was built without encoder weights")
+        assert x.shape[0] == 1 and x.shape[1] == 3
+        if x.shape[2] != 1:
+            raise NotImplementedError("encode() handles a single frame (image-to-video conditioning); video clips: next round")
+        img = x[0].to(self.dev, torch.float32).contiguous()
+        _, _, H, W = img.shape
+        s_ = self.downsample_scale
+        lat = self.enc_cfg["latent_channels"]
+        ts = tile_sample_min_size
+        lib = L.load()
+        tiled = self.use_tiling and (W > ts or H > ts)
+        if not tiled:
+            tiles, i_list, j_list = None, [0], [0]
+        else:
+            overlap = int(ts * 0.75)
+            i_list, j_list = list(range(0, H, overlap)), list(range(0, W, overlap))
+        rows = []
+        for i in i_list:
+            row = []
+            for j in j_list:
+                ph, pw = (min(ts, H - i), min(ts, W - j)) if tiled else (H, W)
+                assert ph % s_ == 0 and pw % s_ == 0
+                key = ("enc", ph // s_, pw // s_)
+                prog = self._programs.get(key)
+                if prog is None:
+                    prog = _TileProgram(self, ph // s_, pw // s_, 1, 1, encoder=True)
+                    self._programs[key] = prog
+                prog.reset()
+                t = torch.empty(1, ph // s_, pw // s_, 64, dtype=torch.bfloat16, device=self.dev)
+                prog.run_encoder_frame(img, i, j, t)
+                row.append(t)
+            rows.append(row)
+        h, w = H // s_, W // s_
+        moments = torch.empty(2 * lat, 1, h, w, dtype=torch.float32, device=self.dev)
+        if not tiled:
+            t = rows[0][0]
+            check(lib.pf_nhwc_to_planar_f32(C.c_void_p(t.data_ptr()), C.c_void_p(moments.data_ptr()), C.c_int(1), C.c_int(h),
+                                            C.c_int(w), C.c_int(64), C.c_int(2 * lat), C.c_int(h), C.c_int(w), C.c_int(h),
+                                            C.c_int(w), C.c_int(0), C.c_int(0), stream()))
+        else:
+            tl = ts // s_
+            blend = int(tl * 0.25)
+            limit = tl - blend
+            y0 = 0
+            for i, row in enumerate(rows):
+                x0 = 0
+                for j, t in enumerate(row):
+                    if i > 0:
+                        self._blend(rows[i - 1][j], t, blend, True, cp=64)
+                    if j > 0:
+                        self._blend(row[j - 1], t, blend, False, cp=64)
+                    ch_, cw_ = min(t.shape[1], limit), min(t.shape[2], limit)
+                    check(lib.pf_nhwc_to_planar_f32(C.c_void_p(t.data_ptr()), C.c_void_p(moments.data_ptr()), C.c_int(1),
+                                                    C.c_int(t.shape[1]), C.c_int(t.shape[2]), C.c_int(64), C.c_int(2 * lat),
+                                                    C.c_int(ch_), C.c_int(cw_), C.c_int(h), C.c_int(w), C.c_int(y0), C.c_int(x0),
+                                                    stream()))
+                    x0 += cw_
+                y0 += min(row[0].shape[1], limit)
+        post = DiagonalGaussianDistribution(moments[None])
+        if not return_dict:
+            return (post,)
+        return EncoderOutput(post)
 
     @torch.no_grad()
     def decode(self, z, is_init_image=True, temporal_chunk=False, return_dict=True, window_size=2, tile_sample_min_size=256):

@@ -142,3 +142,76 @@ def test_mmdit_oracle_vs_reference(ref):
               timestep_ratio=t)[0]
     o = mmdit_forward(sd, TINY_MMDIT, clips, enc, mask, pooled, t)
     assert (r - o).abs().max().item() < 2e-5
+
+
+def test_vae_encode_oracle(ref):
+    """encoder (strided causal convs, single frame and a short clip) + tiled_encode vs the reference."""
+    from oracle import ref_harness as rh
+    from oracle.vae_oracle import vae_encode_moments, posterior_sample
+    v = rh.build_ref_vae()
+    cfg = dict(v.config)
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(1, 3, 1, 64, 96, generator=g).clamp(-1, 1)
+    clip = torch.randn(1, 3, 9, 32, 32, generator=g).clamp(-1, 1)
+    with torch.no_grad():
+        for x in (img, clip):
+            post = v.encode(x).latent_dist
+            o = vae_encode_moments(v.state_dict(), cfg, x)
+            assert (post.parameters - o).abs().max() < 2e-5
+            assert (post.mode() - posterior_sample(o)).abs().max() < 2e-5
+        v.enable_tiling()
+        post = v.encode(img, tile_sample_min_size=32).latent_dist
+        o = vae_encode_moments(v.state_dict(), cfg, img, use_tiling=True, tile_sample_min_size=32)
+        assert post.parameters.shape == o.shape
+        assert (post.parameters - o).abs().max() < 2e-5
+
+
+def test_vae_encoder_key_table(ref):
+    from pyflow_hip import synth
+    v = ref.CausalVideoVAE(encoder_out_channels=16, decoder_in_channels=16,
+                           encoder_block_out_channels=(32, 32, 64, 64), decoder_block_out_channels=(32, 32, 64, 64),
+                           encoder_layers_per_block=(1, 1, 1, 1), decoder_layers_per_block=(2, 2, 2, 2))
+    es = synth.vae_encoder_param_shapes(synth.TINY_VAE_ENC)
+    esd = {k: t for k, t in v.state_dict().items() if k.startswith(("encoder.", "quant_conv."))}
+    assert set(esd) == set(es), set(esd) ^ set(es)
+    assert all(tuple(esd[k].shape) == tuple(s) for k, s in es.items())
+
+
+def test_generate_i2v_oracle_vs_reference(ref):
+    """SD3-style MMDiT + image conditioning: the reference's own generate_i2v (PIL input, torchvision transform stubs,
+    global-RNG posterior draw) vs the oracle (encode -> sample -> normalise -> units 1.. with the video schedule)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import ref_harness as rh
+    from oracle.mmdit_oracle import mmdit_forward
+    from oracle.pipeline_oracle import generate_latents
+    from oracle.vae_oracle import vae_encode_moments, posterior_sample
+    dit = rh.seed_weights(ref.PyramidDiffusionMMDiT(**TINY_MMDIT).eval(), 77)
+    vae = rh.build_ref_vae()
+    pipe = rh.build_ref_pipeline(dit, vae)
+    pipe.model_name = "pyramid_mmdit"
+    pipe.vae_shift_factor, pipe.vae_scale_factor = 0.1490, 1 / 1.8415
+    rh.patch_block_noise(pipe, rh.NoiseStream(1))
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 256, (64, 128, 3), dtype=np.uint8))
+    torch.manual_seed(123)
+    with torch.no_grad():
+        lat_ref = pipe.generate_i2v(prompt="a cat", input_image=img, temp=3, num_inference_steps=[2, 2, 2],
+                                    guidance_scale=7.0, video_guidance_scale=4.0,
+                                    generator=torch.Generator().manual_seed(0), output_type="latent")
+    te = pipe.text_encoder
+    pe, pm, pp = te("a cat, hyper quality, Ultra HD, 8K", None)
+    neg = ("cartoon style, worst quality, low quality, blurry, absolute black, absolute white, low res, extra limbs, "
+           "extra digits, misplaced objects, mutated anatomy, monochrome, horror")
+    ne, nm, npool = te(neg, None)
+    x = (torch.from_numpy(np.asarray(img)).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5
+    moments = vae_encode_moments(vae.state_dict(), dict(vae.config), x[None, :, None])
+    torch.manual_seed(123)
+    eps = torch.randn(1, 16, 1, 8, 16)
+    z = (posterior_sample(moments, eps) - 0.1490) * (1 / 1.8415)
+    init = torch.randn((1, 16, 3, 8, 16), generator=torch.Generator().manual_seed(0))
+    lat = generate_latents(dit.state_dict(), TINY_MMDIT, torch.cat([ne, pe]), torch.cat([nm, pm]), torch.cat([npool, pp]),
+                           init, rh.NoiseStream(1).block_noise, None, [2, 2, 2], 7.0, 4.0,
+                           forward_fn=mmdit_forward, image_latent=z)
+    assert lat.shape == lat_ref.shape == (1, 16, 3, 8, 16)
+    assert (lat - lat_ref).abs().max() < 1e-4
