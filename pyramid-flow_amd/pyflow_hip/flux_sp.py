@@ -98,7 +98,11 @@ class FluxEngineSP(FluxEngine):
                 for b in range(B):
                     ops.patchify(cl[b], tok, (b * L_img + row) * w.in_ch, Cc, t, h, wd, w.in_ch, 0, 1)
             row += n
-        if n_img:
+        if n_img and w.mmdit:     # + sincos position rows of my image tokens (mmdit embedding.py:326-352)
+            ops.gemm(tok, w.x_w, hidden, n_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
+                     strideA=L_img * w.in_ch, strideC=Ld, a_off=lay.img0 * w.in_ch, c_off=n_txt * d,
+                     res=plan.pos, r_off=lay.img0 * d, ldr=d, strideR=0, flags=GEMM_GATE_RES)
+        elif n_img:
             ops.gemm(tok, w.x_w, hidden, n_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
                      strideA=L_img * w.in_ch, strideC=Ld, a_off=lay.img0 * w.in_ch, c_off=n_txt * d)
 
@@ -116,15 +120,19 @@ class FluxEngineSP(FluxEngine):
                 h.wait()
             if mh:
                 ops.qk_norm_rope(recv1, B * mc, mc, 128, 0, *norms, plan.rope, B, L, Lt, mh, q_scale=qs,
-                                 head_stride=lay.HEAD_COLS)
+                                 head_stride=lay.HEAD_COLS, eps=w.qk_eps)
                 ops.v_transpose(recv1, vT, 64, B * mc, mc, B, mh, L, Lp, head_stride=lay.HEAD_COLS)
                 ops.attention(recv1, recv1, vT, obuf, 128, 0, 0, B * mc, mc, B, mh, L, Lp, Lt, plan, scale,
                               q_prescaled=True, head_stride_qk=lay.HEAD_COLS, ldo=B * mh * 64, o_bstride=mh * 64)
 
         for blk in w.dbl:
             mb = blk["mod"]
+            pre_only = blk["pre_only"]         # last MMDiT block: the text stream only feeds the attention
             ln(n_img, n_txt * d, mb + 0, mb + d)
-            ln(n_txt, 0, mb + 6 * d, mb + 7 * d)
+            if pre_only:
+                ln(n_txt, 0, mb + 7 * d, mb + 6 * d)      # AdaLayerNormContinuous: (scale, shift)
+            else:
+                ln(n_txt, 0, mb + 6 * d, mb + 7 * d)
             if n_img:
                 ops.gemm(xn, blk["kvq_img"][0], big, n_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
                          strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d)
@@ -138,12 +146,13 @@ class FluxEngineSP(FluxEngine):
                 ops.gemm(big, blk["o_img"][0], hidden, n_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=n_txt * 3 * d, c_off=n_txt * d, r_off=n_txt * d)
-            if n_txt:
+            if n_txt and not pre_only:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES)
             ln(n_img, n_txt * d, mb + 3 * d, mb + 4 * d)
-            ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
+            if not pre_only:
+                ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
             if n_img:
                 ops.gemm(xn, blk["ff1_img"][0], big, n_img, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, a_off=n_txt * d, c_off=mlp_base + n_txt * 4 * d)
@@ -151,7 +160,7 @@ class FluxEngineSP(FluxEngine):
                          res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + n_txt * 4 * d, c_off=n_txt * d,
                          r_off=n_txt * d)
-            if n_txt:
+            if n_txt and not pre_only:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
                 ops.gemm(big, blk["ff2_txt"][0], hidden, n_txt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     out_path = sys.argv[1]
     heads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    variant = sys.argv[3] if len(sys.argv) > 3 else "flux"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -24,8 +25,13 @@ def main():
     from pyflow_hip.sp import init_sequence_parallel_group
     from util import rel_l2, round_sd
     comm = init_sequence_parallel_group(sp_group_size=world)
-    cfg = dict(synth.TINY_FLUX, num_attention_heads=heads)
-    sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05, lively=True))
+    if variant == "mmdit":
+        cfg = dict(synth.tiny_mmdit_cfg(), num_attention_heads=heads, caption_projection_dim=heads * 64)
+        sd = round_sd(synth.mmdit_state_dict(cfg, seed=3, std=0.05, lively=True))
+        sd["pos_embed.pos_embed"] = synth.mmdit_state_dict(cfg, seed=3)["pos_embed.pos_embed"]
+    else:
+        cfg = dict(synth.TINY_FLUX, num_attention_heads=heads)
+        sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05, lively=True))
     g = torch.Generator().manual_seed(0)
     shapes = [(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)]
     clips = [torch.randn(2, 16, *s, generator=g).to(torch.bfloat16).float().cuda() for s in shapes]

@@ -74,10 +74,10 @@ def _launch(world, script, args, tmp_path):
     print(out.read_text())
 
 
-@pytest.mark.parametrize("world,heads", [(2, 4), (3, 4), (4, 6)])
-def test_sp_multi_process_exchange(tmp_path, world, heads):
-    """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 6 over 4)."""
-    _launch(world, "sp_worker.py", [heads], tmp_path)
+@pytest.mark.parametrize("world,heads,variant", [(2, 4, "flux"), (3, 4, "flux"), (4, 6, "flux"), (3, 4, "mmdit")])
+def test_sp_multi_process_exchange(tmp_path, world, heads, variant):
+    """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 6 over 4); miniFLUX and the SD3-style MMDiT."""
+    _launch(world, "sp_worker.py", [heads, variant], tmp_path)
 
 
 @pytest.mark.parametrize("world", [2, 3])
