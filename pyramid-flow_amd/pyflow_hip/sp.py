@@ -82,6 +82,10 @@ class LocalComm:
     def send(self, t, dst):
         raise RuntimeError("LocalComm has no peers")
 
+    def shift(self, send_t, recv_t):
+        """pass `send_t` to rank+1, receive rank-1's into `recv_t` (no wrap-around): nothing to do on one rank"""
+        return
+
     def recv(self, t, src):
         raise RuntimeError("LocalComm has no peers")
 
@@ -157,6 +161,24 @@ class SPComm:
             dist.send(t.contiguous(), self._global(dst), group=self.group)
         else:
             dist.send(t.contiguous().cpu(), self._global(dst), group=self.group)
+
+    def shift(self, send_t, recv_t):
+        """halo pass of the temporal context parallelism (video_vae/context_parallel_ops.py:76-114): send `send_t` to
+        rank+1 and receive rank-1's tensor into `recv_t`; no wrap-around (rank 0 receives nothing, the last rank sends
+        nothing).  One grouped isend/irecv pair, so neither side can block the other."""
+        staged = not (self.native or send_t.device.type == "cpu")
+        ops, hr = [], None
+        if self.rank + 1 < self.world:
+            s_ = send_t.contiguous()
+            ops.append(dist.P2POp(dist.isend, s_.cpu() if staged else s_, self._global(self.rank + 1), self.group))
+        if self.rank > 0:
+            hr = torch.empty(recv_t.shape, dtype=recv_t.dtype) if staged else recv_t
+            ops.append(dist.P2POp(dist.irecv, hr, self._global(self.rank - 1), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged and hr is not None:
+            recv_t.copy_(hr)
 
     def recv(self, t, src):
         if self.native or t.device.type == "cpu":

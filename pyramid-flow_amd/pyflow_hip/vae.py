@@ -33,12 +33,22 @@ class PBuf:
         self.fs = self.Hp * self.Wp * self.Cp
         self.t = torch.zeros((Tmax + 2) * self.fs, dtype=torch.bfloat16, device=device)
         self.cur = 0          # frames valid in slots [2, 2+cur)
+        self.halo = None      # context-parallel mode: comm whose previous rank supplies the two cache slots
 
     def off(self, slot):
         return slot * self.fs + (self.Wp + 1) * self.Cp
 
+    def exchange_halo(self):
+        """temporal context parallelism (cp_pass_from_previous_rank, context_parallel_ops.py:76-114): my last two frames
+        go to rank+1, slots[0:2] <- the last two frames of rank-1 (rank 0 keeps the causal zeros)."""
+        n, fs = self.cur, self.fs
+        assert n >= 2, "context parallelism needs >= 2 frames per rank at every temporal level"
+        self.halo.shift(self.t[n * fs:(n + 2) * fs], self.t[0:2 * fs])
+
     def shift_cache(self):
         """slots[0:2] <- last two of slots[0:2+cur]  (cache_front_feat update, causal_conv.py:132,143)."""
+        if self.halo is not None:
+            return            # context-parallel mode: one pass per rank, the slots are filled by exchange_halo()
         n = self.cur
         fs = self.fs
         if n >= 2:
@@ -79,6 +89,8 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
     """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple.
     down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2."""
     lib = L.load()
+    if cw.kt == 3 and src.halo is not None:
+        src.exchange_halo()
     d = ConvDesc()
     d.X = src.t.data_ptr()
     d.W = cw.w.data_ptr()
@@ -148,6 +160,7 @@ class _TileProgram:
         b = self.bufs.get(name)
         if b is None:
             b = PBuf(name, self.tmax[level_t], H, W, Cc, self.dev)
+            b.halo = getattr(self, "halo", None)
             self.bufs[name] = b
         return b
 
@@ -590,6 +603,62 @@ class CausalVideoVAE:
             comm.recv(blk, r)
             full[:, :, xb:xe] = blk
         return full
+
+    @torch.no_grad()
+    def decode_context_parallel(self, z, comm, affine=(1.0, 0.0, 1.0, 0.0), to_uint8=True):
+        """Temporal context-parallel decode (config C5; the reference wires this up for training only:
+        modeling_causal_vae.py:540-567, context_parallel_ops.py:14-114, CausalConv3d.context_parallel_forward
+        modeling_causal_conv.py:95-114).  The T latent frames are split into contiguous, possibly uneven ranges over the
+        ranks (the reference's _conv_split needs (T-1) % P == 0); every rank decodes its range UN-tiled in one pass, layer
+        by layer in lockstep: before each 3-tap temporal conv the last two frames of the layer input travel to the next
+        rank (one point-to-point message per conv and boundary) and fill that rank's two cache slots; rank 0 keeps the
+        causal zeros and drops the first frame after each temporal upsample, the others keep it (:561-565).
+        Equals the single-process un-tiled decode.  Returns uint8 frames [T_out,H,W,3] (or the bf16 image) on rank 0,
+        None elsewhere."""
+        from .sp import even_split, starts_of
+        assert z.shape[0] == 1
+        zc = z[0].to(self.dev, torch.float32).contiguous()
+        Cc, T, H, W = zc.shape
+        P, r = comm.world, comm.rank
+        counts = even_split(T, P)
+        assert min(counts) >= 2, "context parallelism needs >= 2 latent frames per rank"
+        f0 = starts_of(counts)[r]
+        nt = counts[r]
+        key = ("cp", H, W, nt, r == 0)
+        prog = self._programs.get(key)
+        if prog is None:
+            prog = _TileProgram(self, H, W, nt, nt)
+            prog.halo = comm if P > 1 else None
+            self._programs[key] = prog
+        prog.reset()
+        n_t = sum(self.cfg["temporal_up_sample"])
+        f = 2 ** n_t
+        s_up = 2 ** sum(self.cfg["spatial_up_sample"])
+        t_out = f * nt - (f - 1 if r == 0 else 0)
+        img = torch.empty(t_out, H * s_up, W * s_up, 8, dtype=torch.bfloat16, device=self.dev)
+        got = prog.run_chunk(zc, f0, nt, 0, 0, r == 0, img, 0, affine)
+        assert got == t_out, (got, t_out)
+        lib = L.load()
+        if to_uint8:
+            loc = torch.empty(t_out, H * s_up, W * s_up, 3, dtype=torch.uint8, device=self.dev)
+            check(lib.pf_to_uint8(C.c_void_p(img.data_ptr()), C.c_void_p(loc.data_ptr()), C.c_int(t_out), C.c_int(H * s_up),
+                                  C.c_int(W * s_up), C.c_int(8), C.c_int(H * s_up), C.c_int(W * s_up), C.c_int(H * s_up),
+                                  C.c_int(W * s_up), C.c_int(0), C.c_int(0), stream()))
+        else:
+            loc = img[..., :3].contiguous()
+        if P == 1:
+            return loc
+        # frames are contiguous in time: rank 0 concatenates (conv_gather, context_parallel_ops.py:41-73)
+        if r != 0:
+            comm.send(loc, 0)
+            return None
+        parts = [loc]
+        for p_ in range(1, P):
+            tp = f * counts[p_]
+            part = torch.empty((tp,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=self.dev)
+            comm.recv(part, p_)
+            parts.append(part)
+        return torch.cat(parts, dim=0)
 
     @torch.no_grad()
     def encode(self, x, return_dict=True, is_init_image=True, temporal_chunk=False, window_size=16, tile_sample_min_size=256):

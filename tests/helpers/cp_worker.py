@@ -1,0 +1,59 @@
+"""worker of tests/test_sp_gpu.py::test_vae_context_parallel: P ranks (sharing cuda:0, gloo transport) decode one latent
+clip with temporal context parallelism (halo exchange per conv); rank 0 compares with its own single-process un-tiled
+decode and with the CPU oracle."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, T = sys.argv[1], int(sys.argv[2])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from pyflow_hip import synth
+    from pyflow_hip.sp import SPComm
+    from pyflow_hip.vae import CausalVideoVAE
+    from util import rel_l2, round_sd
+    cfg = synth.TINY_VAE
+    sd = round_sd(synth.random_state_dict(synth.vae_decoder_param_shapes(cfg), seed=5, std=0.05, lively=True))
+    z = torch.randn(1, 16, T, 6, 10, generator=torch.Generator().manual_seed(2))
+    vae = CausalVideoVAE(sd, cfg, "cuda")
+    aff = (1.3, -0.1, 0.9, 0.2)
+    comm = SPComm()
+    u8 = vae.decode_context_parallel(z.cuda(), comm, affine=aff)
+    img = vae.decode_context_parallel(z.cuda(), comm, affine=aff, to_uint8=False)
+    torch.cuda.synchronize()
+    ok = True
+    if rank == 0:
+        from oracle.vae_oracle import vae_decode
+        ocfg = dict(decoder_block_out_channels=cfg["block_out_channels"], decoder_layers_per_block=cfg["layers_per_block"],
+                    decoder_spatial_up_sample=cfg["spatial_up_sample"], decoder_temporal_up_sample=cfg["temporal_up_sample"])
+        zz = z.clone()
+        zz[:, :, :1] = zz[:, :, :1] * aff[0] + aff[1]
+        zz[:, :, 1:] = zz[:, :, 1:] * aff[2] + aff[3]
+        ref = vae_decode(sd, ocfg, zz)                                   # [1,3,T_out,H,W]
+        single = CausalVideoVAE(sd, cfg, "cuda").decode_context_parallel(z.cuda(), type("C", (), dict(world=1, rank=0))(),
+                                                                         affine=aff, to_uint8=False)
+        got = img.float().cpu().permute(3, 0, 1, 2)[None]
+        e_oracle = rel_l2(got, ref)
+        e_single = rel_l2(img.float().cpu(), single.float().cpu())
+        ok = (u8.shape == (1 + 8 * (T - 1), 48, 80, 3)) and e_oracle < 3e-2 and e_single < 2e-3
+        with open(out_path, "w") as f:
+            f.write(f"world={world} T={T} frames={tuple(u8.shape)} rel_l2_vs_oracle={e_oracle:.3e} vs_single={e_single:.3e}\n")
+    else:
+        ok = u8 is None and img is None
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -86,3 +86,47 @@ def test_uneven_all_to_all_over_gloo(world, H, L):
     for p in procs:
         p.join(timeout=60)
     assert all(all(r[1:]) for r in res), res
+
+
+def _cp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyflow_hip import cp
+    cp.initialize_context_parallel(world)
+    T, k = 1 + 4 * world, 1
+    full = torch.arange(2 * 3 * T * 2 * 2, dtype=torch.float32).reshape(2, 3, T, 2, 2)
+    loc = cp.conv_scatter_to_context_parallel_region(full, 2, k)
+    n = (T - k) // world
+    exp = full[:, :, : n + k] if rank == 0 else full[:, :, rank * n + k:(rank + 1) * n + k]
+    ok1 = torch.equal(loc, exp)
+    halo = cp.cp_pass_from_previous_rank(loc, 2, 3)
+    if rank == 0:
+        exp_h = torch.cat([torch.zeros_like(loc[:, :, :2]), loc], dim=2)
+    else:
+        lo = rank * n + k
+        exp_h = full[:, :, lo - 2:(rank + 1) * n + k]
+    ok2 = torch.equal(halo, exp_h)
+    back = cp.conv_gather_from_context_parallel_region(loc, 2, k)
+    ok3 = torch.equal(back, full)
+    q.put((rank, ok1, ok2, ok3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_context_parallel_helpers_over_gloo(world):
+    """split / halo pass / gather of video_vae/context_parallel_ops.py (rank 0 sees [0,0,x...],
+    rank r sees [prev[-2:], x...])."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(all(r[1:]) for r in res), res

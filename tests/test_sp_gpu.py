@@ -84,3 +84,9 @@ def test_sp_multi_process_exchange(tmp_path, world, heads, variant):
 def test_sp_generate_and_tile_parallel_decode(tmp_path, world):
     """whole generate() (3 stages, 3 units) + tile-parallel VAE decode on `world` ranks == single process, bitwise."""
     _launch(world, "sp_pipeline_worker.py", [], tmp_path)
+
+
+@pytest.mark.parametrize("world,T", [(2, 5), (3, 7)])
+def test_vae_context_parallel(tmp_path, world, T):
+    """temporal context-parallel VAE decode (halo exchange per causal conv, uneven frame ranges) == single process"""
+    _launch(world, "cp_worker.py", [T], tmp_path)
