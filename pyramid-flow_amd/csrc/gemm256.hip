@@ -401,7 +401,8 @@ int launch(const Args& a, hipStream_t stream) {
 int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
     if (force < 0) return 0;
     if (force > 0) return (N % force == 0) ? force : 0;
-    const int bn = (N % 256 == 0) ? 256 : ((N % 192 == 0) ? 192 : 0);
+    // N = 128 (the full-resolution VAE convs): the 256x128 tile still halves the A re-reads of the 128x128 kernel
+    const int bn = (N % 256 == 0) ? 256 : ((N % 192 == 0) ? 192 : ((N % 128 == 0 && M_total >= 65536) ? 128 : 0));
     if (!bn) return 0;
     // small problems: the 128x128 tiles (2 blocks / CU) fill the 256 CUs better
     const long long tiles = (long long)((M + BM - 1) / BM) * batch * (N / bn);

@@ -8,6 +8,8 @@ Fused projections: per double block K|V|Q share one GEMM per stream; per single 
 (N = 7d) with the GELU fused on the MLP columns; attention writes O over the Q columns so that the
 out-projection reads `[O | mlp]` (= the reference's `cat([attn, mlp])`, flux_block.py:936) in place.
 """
+import contextlib
+
 import torch
 
 from . import ops
@@ -176,6 +178,13 @@ class FluxEngine:
         self._ws = {}
         self._ctx = None
         self._mod_cache = None
+        self.overlap_text = True        # text stream of the double blocks on a side HIP stream
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     # ---- workspace (grow-only) ----
     def _buf(self, name, numel, dtype):
@@ -298,44 +307,64 @@ class FluxEngine:
         def ln(rows, x_off, sh, sc):
             ops.ln_modulate(hidden, xn, (mod, sh), (mod, sc), d, B, rows, Ld, Ld, d, d, nm, x_off=x_off, y_off=x_off)
 
+        # The text stream of a double block (rows [0, Lt): 6 small GEMMs, 2 workgroup waves on 256 CUs) is independent
+        # of the image stream between the two joins around the attention: it runs on a side HIP stream and fills CUs
+        # the image GEMMs' tails leave idle.  Rows / buffer regions of the two streams are disjoint.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if (self.overlap_text and w.dbl) else None
+        if side is not None:
+            side.wait_stream(main)
+
+        def on_side():
+            return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
         for blk in w.dbl:
             mb = blk["mod"]
             pre_only = blk["pre_only"]
+            with on_side():
+                if pre_only:          # AdaLayerNormContinuous: (scale, shift) = chunks 0, 1 of the 2d modulation
+                    ln(Lt, 0, mb + 7 * d, mb + 6 * d)
+                else:
+                    ln(Lt, 0, mb + 6 * d, mb + 7 * d)
+                ops.gemm(xn, blk["kvq_txt"][0], big, Lt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
+                         strideA=Ld, strideC=L3)
             ln(L_img, Lt * d, mb + 0, mb + d)
-            if pre_only:          # AdaLayerNormContinuous: (scale, shift) = chunks 0, 1 of the 2d modulation
-                ln(Lt, 0, mb + 7 * d, mb + 6 * d)
-            else:
-                ln(Lt, 0, mb + 6 * d, mb + 7 * d)
             ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
                      strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
-            ops.gemm(xn, blk["kvq_txt"][0], big, Lt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
-                     strideA=Ld, strideC=L3)
+            if side is not None:
+                main.wait_stream(side)
             ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
                              blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
             ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
+            if side is not None:
+                side.wait_stream(main)
+            if not pre_only:
+                with on_side():
+                    ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
+                             gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
+                             flags=GEMM_GATE_RES, a_off=2 * d)
+                    ln(Lt, 0, mb + 9 * d, mb + 10 * d)
+                    ops.gemm(xn, blk["ff1_txt"][0], big, Lt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
+                             strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
+                    ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
+                             res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
+                             gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
             ops.gemm(big, blk["o_img"][0], hidden, L_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=Lt * 3 * d + 2 * d, c_off=Lt * d, r_off=Lt * d)
-            if not pre_only:
-                ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
-                         gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
-                         flags=GEMM_GATE_RES, a_off=2 * d)
-                ln(Lt, 0, mb + 9 * d, mb + 10 * d)
             ln(L_img, Lt * d, mb + 3 * d, mb + 4 * d)
             ops.gemm(xn, blk["ff1_img"][0], big, L_img, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
                      strideA=Ld, strideC=L4, gelu_from=0, a_off=Lt * d, c_off=mlp_base + Lt * 4 * d)
             ops.gemm(big, blk["ff2_img"][0], hidden, L_img, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                      res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                      gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + Lt * 4 * d, c_off=Lt * d, r_off=Lt * d)
-            if not pre_only:
-                ops.gemm(xn, blk["ff1_txt"][0], big, Lt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
-                         strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
-                ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
-                         res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
             if debug is not None and "hidden_d0" not in debug:
+                if side is not None:
+                    main.wait_stream(side)
                 debug["hidden_d0"] = hidden[:B * L * d].view(B, L, d).clone()
+        if side is not None:
+            main.wait_stream(side)
 
         for blk in w.sgl:
             mb = blk["mod"]

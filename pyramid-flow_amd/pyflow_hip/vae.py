@@ -434,6 +434,8 @@ class CausalVideoVAE:
                 b[:top] = sd[a + n + ".bias"]
                 store[n] = (w.to(self.dev, torch.bfloat16).contiguous(), b.to(self.dev))
         self._programs = {}
+        self.n_streams = 4          # concurrent tile decodes (HIP streams); 1 = strictly sequential
+        self._streams = []
 
     def enable_tiling(self, use_tiling=True):
         self.use_tiling = use_tiling
@@ -456,23 +458,28 @@ class CausalVideoVAE:
             sizes.append(num_frames - fid)
         return sizes
 
-    def _program(self, th, tw, sizes):
-        key = (th, tw, sizes[0], max(sizes[1:] or [sizes[0]]))
+    def _program(self, th, tw, sizes, lane=0):
+        key = (th, tw, sizes[0], max(sizes[1:] or [sizes[0]]), lane)
         p = self._programs.get(key)
         if p is None:
             p = _TileProgram(self, th, tw, key[2], key[3])
             self._programs[key] = p
         return p
 
-    def _decode_tile(self, z, h0, w0, th, tw, sizes, affine):
+    def _tile_out(self, T, th, tw):
+        f = 2 ** sum(self.cfg["temporal_up_sample"])
+        s = 2 ** sum(self.cfg["spatial_up_sample"])
+        return torch.empty(1 + f * (T - 1), th * s, tw * s, 8, dtype=torch.bfloat16, device=self.dev)
+
+    def _decode_tile(self, z, h0, w0, th, tw, sizes, affine, out=None, lane=0):
         """-> bf16 [T_out, 8 th, 8 tw, 8] (channels 0..2 valid)."""
         T = z.shape[1]
         n_t = sum(self.cfg["temporal_up_sample"])
         f = 2 ** n_t
         T_out = 1 + f * (T - 1)
-        s = 2 ** sum(self.cfg["spatial_up_sample"])
-        out = torch.empty(T_out, th * s, tw * s, 8, dtype=torch.bfloat16, device=self.dev)
-        prog = self._program(th, tw, sizes)
+        if out is None:
+            out = self._tile_out(T, th, tw)
+        prog = self._program(th, tw, sizes, lane)
         prog.reset()
         t0, fo = 0, 0
         for ci, nt in enumerate(sizes):
@@ -520,7 +527,32 @@ class CausalVideoVAE:
         c0 = starts_of(ncols)[rank]
         my_js = j_list[c0:c0 + ncols[rank]]
         self.tile_cols = (c0, ncols[rank], len(j_list))
-        rows = [[self._decode_tile(z, i, j, min(tl, H - i), min(tl, W - j), sizes, affine) for j in my_js] for i in i_list]
+        # the tiles are independent until the blend: decode them round-robin on a few HIP streams (each with its own
+        # buffer set), so that the small latent-resolution layers of one tile -- 32 workgroups on 256 CUs -- overlap
+        # with the large layers of another
+        rows = [[self._tile_out(T, min(tl, H - i), min(tl, W - j)) for j in my_js] for i in i_list]
+        ns = max(1, min(self.n_streams, len(i_list) * len(my_js)))
+        if ns == 1:
+            for a, i in enumerate(i_list):
+                for b, j in enumerate(my_js):
+                    self._decode_tile(z, i, j, min(tl, H - i), min(tl, W - j), sizes, affine, out=rows[a][b])
+        else:
+            if len(self._streams) < ns:
+                self._streams += [torch.cuda.Stream(device=self.dev) for _ in range(ns - len(self._streams))]
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            k = 0
+            for a, i in enumerate(i_list):
+                for b, j in enumerate(my_js):
+                    st = self._streams[k % ns]
+                    if k < ns:
+                        st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        self._decode_tile(z, i, j, min(tl, H - i), min(tl, W - j), sizes, affine, out=rows[a][b], lane=k % ns)
+                    k += 1
+            for st in self._streams[:ns]:
+                cur.wait_stream(st)
         has_left = world > 1 and c0 > 0 and ncols[rank] > 0
         # the next rank that owns columns (ranks beyond the column count own none)
         nxt = rank + 1 if (world > 1 and rank + 1 < world and ncols[rank + 1] > 0 and ncols[rank] > 0) else None

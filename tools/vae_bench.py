@@ -1,0 +1,27 @@
+"""CausalVideoVAE decode benchmark at the C3 / C5 shape: latent [1,16,31,96,160] -> 241 x 768 x 1280 uint8 frames,
+reference mode tiled(256) / chunked(1).  usage: vae_bench.py [n_streams ...]"""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+from pyflow_hip import synth, ops
+from pyflow_hip.vae import CausalVideoVAE
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(1)
+sd = {}
+for k, shp in synth.vae_decoder_param_shapes(synth.VAE_DEFAULT).items():
+    sd[k] = (torch.ones(shp, device=dev) if k.endswith(".weight") else torch.zeros(shp, device=dev)) if len(shp) == 1 \
+        else torch.randn(shp, generator=g, device=dev) * 0.02
+vae = CausalVideoVAE(sd, synth.VAE_DEFAULT, dev)
+vae.enable_tiling()
+T = int(os.environ.get("VAE_T", 31))
+z = torch.randn(1, 16, T, 96, 160, device=dev)
+for ns in [int(a) for a in sys.argv[1:]] or [1, 4]:
+    vae.n_streams = ns
+    vae.decode_to_uint8(z[:, :, :2], window_size=1, tile_sample_min_size=256)      # warm-up / allocations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"n_streams={ns}: {dt:.2f} s for {out.shape[0]} frames ({7.51e15 * (out.shape[0] / 241) / dt / 1e12:.0f} TFLOP/s conv-equivalent) "
+          f"checksum {int(out[::16, ::64, ::64].sum())}", flush=True)
