@@ -99,6 +99,8 @@ typedef struct {
     float scale;
     int head_stride_qk; /* elements between consecutive heads inside a Q / K row (0 or 64 = packed heads; 192 in the
                           head-major [k|v|q] layout of the sequence-parallel exchange buffers) */
+    int q_row_begin;   /* query rows below this index are not needed (their O rows are left untouched; rounded down to a
+                          multiple of 128): the last block only feeds the current frame's rows to the output */
     int q_prescaled;   /* 1: Q was already multiplied by scale*log2(e) (pf_qk_norm_rope q_scale): `scale` is ignored and
                           the scores are used as base-2 exponents directly (saves one FMA per score) */
 } pf_attn_desc;

@@ -32,6 +32,7 @@ struct AArgs {
     long long sQ, sK, sO, sVb, sVh;
     int Lp, L, H, B, Lt, nqt;
     int hs_qk;             // elements between consecutive heads in Q and K (64 = packed heads)
+    int qt0;               // first 128-row query tile to compute (rows below are not needed by the caller)
     const int* a_lo; const int* a_hi; const int* b_hi;
     const int* tile_kv_end;
     float sc;   // softmax scale * log2(e)
@@ -42,10 +43,11 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = p.nqt * p.H * p.B;
+    const int nq_run = p.nqt - p.qt0;
+    const int nwg = nq_run * p.H * p.B;
     int t = xcd_remap(blockIdx.x, nwg);
-    const int bh = t / p.nqt;
-    const int qt = p.nqt - 1 - (t - bh * p.nqt);      // heaviest (latest) q tiles first
+    const int bh = t / nq_run;
+    const int qt = p.nqt - 1 - (t - bh * nq_run);     // heaviest (latest) q tiles first
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qt * QB;
     const int frow = lane & 31, hi = lane >> 5, swz = (lane >> 1) & 7;
@@ -321,7 +323,9 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.sc = d->scale * 1.4426950408889634f;
     a.hs_qk = d->head_stride_qk > 0 ? d->head_stride_qk : HD;
     if (a.hs_qk % 8) return pf_set_err("pf_attention_bf16: head_stride_qk must be a multiple of 8");
-    const int grid = a.nqt * a.H * a.B;
+    a.qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
+    if (a.qt0 >= a.nqt) return pf_set_err("pf_attention_bf16: q_row_begin beyond the sequence");
+    const int grid = (a.nqt - a.qt0) * a.H * a.B;
     if (d->q_prescaled) hipLaunchKernelGGL(attn_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();

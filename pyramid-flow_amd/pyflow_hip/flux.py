@@ -179,6 +179,7 @@ class FluxEngine:
         self._ctx = None
         self._mod_cache = None
         self.overlap_text = True        # text stream of the double blocks on a side HIP stream
+        self.skip_dead_rows = True      # last block: Q / MLP / attention / proj_out only for the current frame's rows
         self._side = None
 
     def _side_stream(self):
@@ -366,9 +367,28 @@ class FluxEngine:
         if side is not None:
             main.wait_stream(side)
 
-        for blk in w.sgl:
+        n_cur = plan.n_cur
+        for bi, blk in enumerate(w.sgl):
             mb = blk["mod"]
             ln(L, 0, mb, mb + d)
+            if self.skip_dead_rows and bi == len(w.sgl) - 1 and n_cur < L:
+                # LAST block: only the current frame's rows reach the output (split_output keeps [-n_cur:],
+                # modeling_pyramid_flux.py:380).  K and V are still needed for every row, but Q, the MLP branch,
+                # the attention rows and proj_out only for the last n_cur rows -- identical values, less work.
+                r0 = L - n_cur
+                ops.gemm(xn, blk["kvqm"][0], big, L, 2 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
+                         strideC=L7)
+                ops.gemm(xn, blk["kvqm"][0], big, n_cur, 5 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
+                         strideC=L7, gelu_from=d, a_off=r0 * d, c_off=r0 * 7 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d)
+                ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H,
+                                 q_scale=qs, eps=w.qk_eps)
+                ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
+                ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
+                              q_row_begin=r0)
+                ops.gemm(big, blk["out"][0], hidden, n_cur, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
+                         gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
+                         flags=GEMM_GATE_RES, a_off=r0 * 7 * d + 2 * d, c_off=r0 * d, r_off=r0 * d)
+                continue
             ops.gemm(xn, blk["kvqm"][0], big, L, 7 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
                      strideC=L7, gelu_from=3 * d)
             ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H, q_scale=qs)
@@ -381,7 +401,6 @@ class FluxEngine:
             debug["hidden_final"] = hidden[:B * L * d].view(B, L, d).clone()
 
         # ---- norm_out + proj_out on the current frame's tokens only (split_output keeps [-n_cur:], flux:380) ----
-        n_cur = plan.n_cur
         fo = (L - n_cur) * d
         mf = w.mod_final
         ops.ln_modulate(hidden, xn, (mod, mf + d), (mod, mf), d, B, n_cur, Ld, Ld, d, d, nm, x_off=fo, y_off=fo)

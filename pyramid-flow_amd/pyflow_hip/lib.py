@@ -44,7 +44,7 @@ class AttnDesc(C.Structure):
                 ("strideVt_b", C.c_longlong), ("strideVt_h", C.c_longlong),
                 ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("Lp", C.c_int), ("Lt", C.c_int),
                 ("a_lo", C.c_void_p), ("a_hi", C.c_void_p), ("b_hi", C.c_void_p), ("tile_kv_end", C.c_void_p),
-                ("scale", C.c_float), ("head_stride_qk", C.c_int), ("q_prescaled", C.c_int)]
+                ("scale", C.c_float), ("head_stride_qk", C.c_int), ("q_row_begin", C.c_int), ("q_prescaled", C.c_int)]
 
 
 GEMM_GATE_RES = 1

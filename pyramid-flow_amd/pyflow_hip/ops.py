@@ -68,7 +68,7 @@ LOG2E = 1.4426950408889634
 
 
 def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale, q_prescaled=False,
-              head_stride_qk=0, ldo=None, o_bstride=None):
+              head_stride_qk=0, ldo=None, o_bstride=None, q_row_begin=0):
     lib = L.load()
     d = AttnDesc()
     d.Q = Q.data_ptr() + 2 * q_off
@@ -80,6 +80,7 @@ def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt,
     d.strideQ = d.strideK = bstride
     d.strideO = bstride if o_bstride is None else o_bstride
     d.head_stride_qk = head_stride_qk
+    d.q_row_begin = q_row_begin
     d.strideVt_b = H * 64 * Lp
     d.strideVt_h = 64 * Lp
     d.B, d.H, d.L, d.Lp, d.Lt = B, H, Lseq, Lp, Lt
@@ -87,7 +88,7 @@ def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt,
     d.tile_kv_end = plan.tile_kv_end.data_ptr()
     d.scale = scale
     d.q_prescaled = int(q_prescaled)
-    PROFILER.launch("attention", 4.0 * plan.useful_pairs() * 64 * H,
+    PROFILER.launch("attention", 4.0 * plan.useful_pairs(q_row_begin) * 64 * H,
                     lambda: check(lib.pf_attention_bf16(C.byref(d), stream())))
 
 

@@ -95,9 +95,12 @@ class SequencePlan:
         a_lo, a_hi, b_hi = (self.host[k][:, :, None] for k in ("a_lo", "a_hi", "b_hi"))
         return np.where(j < self.Lt, (j >= a_lo) & (j < a_hi), j < b_hi)
 
-    def useful_pairs(self):
-        """number of unmasked (q, k) pairs summed over the batch (for FLOP accounting)."""
-        if getattr(self, "_pairs", None) is None:
+    def useful_pairs(self, q_row_begin=0):
+        """number of unmasked (q, k) pairs summed over the batch for query rows >= q_row_begin (FLOP accounting)."""
+        cache = self.__dict__.setdefault("_pairs", {})
+        if q_row_begin not in cache:
             h = self.host
-            self._pairs = int((h["a_hi"] - h["a_lo"]).astype(np.int64).sum() + (h["b_hi"] - self.Lt).astype(np.int64).sum())
-        return self._pairs
+            r = q_row_begin
+            cache[q_row_begin] = int((h["a_hi"][:, r:] - h["a_lo"][:, r:]).astype(np.int64).sum()
+                                     + (h["b_hi"][:, r:] - self.Lt).astype(np.int64).sum())
+        return cache[q_row_begin]
