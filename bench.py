@@ -24,17 +24,22 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (height, width, temp, steps_first, steps_video)
     "c3_768p_241f": (768, 1280, 31, [20, 20, 20], [10, 10, 10]),
+    # config C4: SD3-style MMDiT image-to-video, VAE encode + decode in the loop (generate_i2v, temp 16 -> 121 frames)
+    "c4_i2v_768p_121f": (768, 1280, 16, [10, 10, 10], [10, 10, 10]),
     "c2_384p_121f": (384, 640, 16, [20, 20, 20], [10, 10, 10]),
     "smoke_128p_17f": (128, 192, 3, [4, 4, 4], [2, 2, 2]),
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def build_pipeline(device, tiny=False):
+def build_pipeline(device, tiny=False, mmdit=False):
     from pyflow_hip import synth
     from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
-    dcfg = synth.TINY_FLUX if tiny else synth.MINIFLUX
-    vcfg = synth.TINY_VAE if tiny else synth.VAE_DEFAULT
+    if mmdit:
+        dcfg = synth.tiny_mmdit_cfg() if tiny else synth.SD3_MMDIT
+    else:
+        dcfg = synth.TINY_FLUX if tiny else synth.MINIFLUX
+    vcfg = dict(synth.TINY_VAE if tiny else synth.VAE_DEFAULT)
     g = torch.Generator(device=device).manual_seed(1234)
 
     def rand_sd(shapes):
@@ -46,10 +51,20 @@ def build_pipeline(device, tiny=False):
             else:
                 sd[k] = torch.randn(shp, generator=g, device=device) * 0.02
         return sd
-    dsd = rand_sd(synth.flux_param_shapes(dcfg))
+    if mmdit:
+        dsd = rand_sd({k: v for k, v in synth.mmdit_param_shapes(dcfg).items() if k != "pos_embed.pos_embed"})
+        d = dcfg["num_attention_heads"] * dcfg["attention_head_dim"]
+        dsd["pos_embed.pos_embed"] = synth.sincos_2d_table(d, dcfg["pos_embed_max_size"], dcfg["sample_size"] // dcfg["patch_size"])[None]
+    else:
+        dsd = rand_sd(synth.flux_param_shapes(dcfg))
     vsd = rand_sd(synth.vae_decoder_param_shapes(vcfg))
+    if mmdit:        # image-to-video needs the encoder
+        ecfg = synth.TINY_VAE_ENC if tiny else synth.VAE_ENC_DEFAULT
+        vsd.update(rand_sd(synth.vae_encoder_param_shapes(ecfg)))
+        vcfg.update(ecfg)
     pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=dcfg, vae_state_dict=vsd, vae_config=vcfg,
-                                        model_name="pyramid_flux", model_dtype="bf16", device=device)
+                                        model_name="pyramid_mmdit" if mmdit else "pyramid_flux", model_dtype="bf16",
+                                        device=device)
     pipe.vae.enable_tiling()                      # reference inference setup (inference_multigpu.py:52-55)
     return pipe, dcfg, dsd
 
@@ -159,12 +174,18 @@ def main():
             init_sequence_parallel_group(sp_group_size=world)
 
     H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
-    pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model)
+    i2v = args.workload.startswith("c4")
+    pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model, mmdit=i2v)
     embeds = synthetic_prompt(dcfg, device)
+    image = torch.randn(3, H, W, generator=torch.Generator().manual_seed(77)).clamp(-1, 1)
     sp = SampledProfiler(pipe, args.profile_period)
     frames_per_video = 1 + 8 * (temp - 1)
 
     def one_video(seed):
+        if i2v:
+            return pipe.generate_i2v(prompt_embeds=embeds, input_image=image, temp=temp, num_inference_steps=stepsv,
+                                     guidance_scale=7.0, video_guidance_scale=4.0,
+                                     generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
         return pipe.generate(prompt_embeds=embeds, height=H, width=W, temp=temp, num_inference_steps=steps1,
                              video_num_inference_steps=stepsv, guidance_scale=7.0, video_guidance_scale=5.0,
                              generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
@@ -242,7 +263,12 @@ def main():
         "roofline": roof,
         "roofline_other_kernels": extra,
     }
-    if not args.no_cpu_baseline and world == 1 and not args.tiny_model:
+    if i2v:
+        res["metric"] = "video frames/sec for 768p image-to-video sampling (config C4, not the headline metric)"
+        res["config"]["workload"] = (f"{args.workload}: SD3-style MMDiT (24 joint blocks, d=1536) generate_i2v + CausalVideoVAE "
+                                     f"tiled encode / decode, {H}x{W}, temp={temp} ({frames_per_video} frames), steps {stepsv}, "
+                                     "CFG 7.0/4.0, random-init weights, synthetic prompt embeddings and image")
+    if not args.no_cpu_baseline and world == 1 and not args.tiny_model and not i2v:
         res["cpu_baseline"] = cpu_baseline(dcfg, dsd, os.cpu_count() or 1)
     print(json.dumps(res))
 

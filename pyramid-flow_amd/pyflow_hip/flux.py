@@ -319,25 +319,38 @@ class FluxEngine:
         def on_side():
             return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
 
+        n_cur = plan.n_cur
         for blk in w.dbl:
             mb = blk["mod"]
             pre_only = blk["pre_only"]
+            # last MMDiT block (context_pre_only, no single blocks follow): only the current frame's rows reach the
+            # output -> K, V for every row, but Q / attention rows / to_out / MLP only for the last n_cur image rows
+            tail = pre_only and self.skip_dead_rows and not w.sgl and n_cur < L_img
+            r0 = L - n_cur if tail else Lt                      # first image row that is computed in full
+            n_act = L - r0
             with on_side():
                 if pre_only:          # AdaLayerNormContinuous: (scale, shift) = chunks 0, 1 of the 2d modulation
                     ln(Lt, 0, mb + 7 * d, mb + 6 * d)
                 else:
                     ln(Lt, 0, mb + 6 * d, mb + 7 * d)
-                ops.gemm(xn, blk["kvq_txt"][0], big, Lt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
-                         strideA=Ld, strideC=L3)
+                ops.gemm(xn, blk["kvq_txt"][0], big, Lt, (2 if tail else 3) * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1],
+                         batch=B, strideA=Ld, strideC=L3)
             ln(L_img, Lt * d, mb + 0, mb + d)
-            ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                     strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
+            if tail:
+                ops.gemm(xn, blk["kvq_img"][0], big, L_img, 2 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
+                ops.gemm(xn, blk["kvq_img"][0], big, n_act, d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                         strideA=Ld, strideC=L3, a_off=r0 * d, c_off=r0 * 3 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d)
+            else:
+                ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
             if side is not None:
                 main.wait_stream(side)
             ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
                              blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
             ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
-            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
+            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
+                          q_row_begin=r0 if tail else 0)
             if side is not None:
                 side.wait_stream(main)
             if not pre_only:
@@ -351,15 +364,15 @@ class FluxEngine:
                     ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
                              res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                              gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
-            ops.gemm(big, blk["o_img"][0], hidden, L_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
+            ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
-                     flags=GEMM_GATE_RES, a_off=Lt * 3 * d + 2 * d, c_off=Lt * d, r_off=Lt * d)
-            ln(L_img, Lt * d, mb + 3 * d, mb + 4 * d)
-            ops.gemm(xn, blk["ff1_img"][0], big, L_img, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
-                     strideA=Ld, strideC=L4, gelu_from=0, a_off=Lt * d, c_off=mlp_base + Lt * 4 * d)
-            ops.gemm(big, blk["ff2_img"][0], hidden, L_img, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
+                     flags=GEMM_GATE_RES, a_off=r0 * 3 * d + 2 * d, c_off=r0 * d, r_off=r0 * d)
+            ln(n_act, r0 * d, mb + 3 * d, mb + 4 * d)
+            ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
+                     strideA=Ld, strideC=L4, gelu_from=0, a_off=r0 * d, c_off=mlp_base + r0 * 4 * d)
+            ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                      res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + Lt * 4 * d, c_off=Lt * d, r_off=Lt * d)
+                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + r0 * 4 * d, c_off=r0 * d, r_off=r0 * d)
             if debug is not None and "hidden_d0" not in debug:
                 if side is not None:
                     main.wait_stream(side)
