@@ -15,6 +15,7 @@
 // because the contraction-slot -> key permutation of the C layout is mirrored in the V^T image
 // (pf_v_transpose writes keys permuted within groups of 16).  K and V^T tiles arrive by LDS-DMA
 // with source-side XOR swizzle, double-buffered, one barrier per KV tile.
+#include <stdlib.h>
 #include "common.h"
 #include "pyflow_hip.h"
 
@@ -33,13 +34,14 @@ struct AArgs {
     int Lp, L, H, B, Lt, nqt;
     int hs_qk;             // elements between consecutive heads in Q and K (64 = packed heads)
     int qt0;               // first 128-row query tile to compute (rows below are not needed by the caller)
+    int prio;              // tuning hook (PF_ATTN_PRIO): 0 no s_setprio, 1 around the MFMA groups, 2 around the softmax
     const int* a_lo; const int* a_hi; const int* b_hi;
     const int* tile_kv_end;
     float sc;   // softmax scale * log2(e)
 };
 
-template <bool PRE>
-__global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
+template <bool PRE, int ILP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_kernel(const AArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
             for (int i = 0; i < 2; ++i) kf[i][ks] = *(const bf16x8_t*)(sk + (i * 32 + frow) * 128 + ch);
         }
         f32x16_t s[2];
-        __builtin_amdgcn_s_setprio(1);
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
         if (PRE) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][0], qf[0], negm, 0, 0, 0);
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
         for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][ks], qf[ks], s[i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(0);
+        if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
         // ---- V^T fragments are requested now and land under the softmax arithmetic
         bf16x8_t vf[2][4];
 #pragma unroll
@@ -167,11 +170,28 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
                     s[i][r] = ok ? s[i][r] : NINF;      // exp2(-inf) == 0: no select needed after the exponential
                 }
         }
-        float mt = s[0][0];
+        float mt;
+        if (ILP == 1) {
+            mt = s[0][0];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[i][r]);
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[i][r]);
+        } else {                      // ILP independent max chains instead of one 32-long dependent chain
+            float mq[ILP];
+#pragma unroll
+            for (int c = 0; c < ILP; ++c) mq[c] = s[(c * (32 / ILP)) >> 4][(c * (32 / ILP)) & 15];
+#pragma unroll
+            for (int e = 0; e < 32 / ILP; ++e)
+#pragma unroll
+                for (int c = 0; c < ILP; ++c) {
+                    const int idx = c * (32 / ILP) + e;
+                    mq[c] = fmaxf(mq[c], s[idx >> 4][idx & 15]);
+                }
+            mt = mq[0];
+#pragma unroll
+            for (int c = 1; c < ILP; ++c) mt = fmaxf(mt, mq[c]);
+        }
         {   // the row's other 32 keys live in lane ^ 32
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
             mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -194,14 +214,19 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm[r] = -m;
             }
+            float pq[ILP];
+#pragma unroll
+            for (int c = 0; c < ILP; ++c) pq[c] = 0.f;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float e = __builtin_amdgcn_exp2f(s[i][r]);
                     s[i][r] = e;
-                    ps += e;
+                    pq[r % ILP] += e;
                 }
+#pragma unroll
+            for (int c = 0; c < ILP; ++c) ps += pq[c];
         } else {
             // ---- deferred rescale: keep the running max while no row of the wave grew by more than 2^DEFER
             if (__builtin_amdgcn_ballot_w64((mt - m) * p.sc > DEFER) != 0) {
@@ -230,12 +255,13 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(const AArgs p) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[g][e] = (bf16_t)s[g >> 1][8 * (g & 1) + e];
-        __builtin_amdgcn_s_setprio(1);
+        if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 2; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][g], pf[g], o[i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(0);
     }
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -323,11 +349,18 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.sc = d->scale * 1.4426950408889634f;
     a.hs_qk = d->head_stride_qk > 0 ? d->head_stride_qk : HD;
     if (a.hs_qk % 8) return pf_set_err("pf_attention_bf16: head_stride_qk must be a multiple of 8");
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("PF_ATTN_PRIO"); prio = e ? atoi(e) : 1; }
+    a.prio = prio;
     a.qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
     if (a.qt0 >= a.nqt) return pf_set_err("pf_attention_bf16: q_row_begin beyond the sequence");
     const int grid = (a.nqt - a.qt0) * a.H * a.B;
-    if (d->q_prescaled) hipLaunchKernelGGL(attn_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+    static int var = -1;      // tuning hook PF_ATTN_VAR: 0 = 1 chain / 3 waves per SIMD, 1 = 2 chains / 3, 2 = 4 chains / 2
+    if (var < 0) { const char* e = getenv("PF_ATTN_VAR"); var = e ? atoi(e) : 0; }
+    if (!d->q_prescaled) hipLaunchKernelGGL((attn_kernel<false, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
+    else if (var == 1) hipLaunchKernelGGL((attn_kernel<true, 2, 3>), dim3(grid), dim3(256), 0, stream, a);
+    else if (var == 2) hipLaunchKernelGGL((attn_kernel<true, 4, 2>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_kernel<true, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));
     return 0;
