@@ -61,3 +61,23 @@ def test_generate_frames_vs_oracle():
     psnr = 10 * torch.log10(torch.tensor(255.0 ** 2 / max(mse, 1e-9))).item()
     print("PSNR vs oracle frames:", psnr)
     assert psnr >= 35.0
+
+
+def test_one_stage_image_generation_vs_oracle():
+    """config C1 plumbing: single pyramid stage (stages=[1], stage_range=[0,1]), temp = 1 text-to-image, latents vs the
+    CPU oracle on identical noise."""
+    from pyflow_hip import synth
+    from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
+    from oracle.pipeline_oracle import generate_latents
+    g = torch.load(GOLD)
+    dsd = round_sd(synth.random_state_dict(synth.flux_param_shapes(g["dit_cfg"]), seed=g["dit_weight_seed"], std=0.05, lively=True))
+    pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=g["dit_cfg"], model_name="pyramid_flux", load_vae=False,
+                                        stages=[1], stage_range=[0, 1], sample_ratios=[1])
+    lat = pipe.generate(prompt_embeds=_embeds(g), height=128, width=128, temp=1, num_inference_steps=[4],
+                        video_num_inference_steps=[4], guidance_scale=9.0, video_guidance_scale=9.0,
+                        generator=torch.Generator().manual_seed(3), output_type="latent")
+    init = torch.randn((1, 16, 1, 16, 16), generator=torch.Generator().manual_seed(3))
+    ref = generate_latents(dsd, g["dit_cfg"], g["prompt_embeds"], g["prompt_mask"], g["pooled"], init, None, [4], [4], 9.0, 9.0,
+                           stages=(1,), sched_kwargs=dict(stages=1, stage_range=[0, 1]))
+    assert lat.shape == ref.shape == (1, 16, 1, 16, 16)
+    assert rel_l2(lat.float().cpu(), ref) < 5e-2
