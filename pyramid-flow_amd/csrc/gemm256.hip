@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
     const int g = wid >> 2, w4 = wid & 3, wm = w4 >> 1, wn = w4 & 1;
 
     // ---- tile mapping
-    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;      // N tail: clamped loads, masked stores
     const int TM = tiles_m * p.batch;
     const int nwg = TM * tiles_n;
     int t = xcd_remap(blockIdx.x, nwg);
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
     for (int j = 0; j < NT; ++j) {
         const int ib = g * (BN / 16) + w4 * NT + j;
         const int c = (lane & 7) ^ (((ib & 1) << 2) + (lane >> 4));
-        bsrc[j] = p.W + (long long)(n0 + 8 * ib + (lane >> 3)) * p.ldw + c * 8;
+        int nrow = n0 + 8 * ib + (lane >> 3);
+        nrow = nrow < p.N ? nrow : p.N - 1;
+        bsrc[j] = p.W + (long long)nrow * p.ldw + c * 8;
     }
     const int nk = p.K / BK;
 
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
 
 template <int BN, bool CONV, int V>
 int launch(const Args& a, hipStream_t stream) {
-    const int grid = (a.N / BN) * ((a.M + BM - 1) / BM) * a.batch;
+    const int grid = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm256_kernel<BN, CONV, V>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -400,12 +402,18 @@ int launch(const Args& a, hipStream_t stream) {
 // force: 0 auto, 128/192/256 = that width if it divides N, -1 = never.
 int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
     if (force < 0) return 0;
-    if (force > 0) return (N % force == 0) ? force : 0;
-    // N = 128 (the full-resolution VAE convs): the 256x128 tile still halves the A re-reads of the 128x128 kernel
-    const int bn = (N % 256 == 0) ? 256 : ((N % 192 == 0) ? 192 : ((N % 128 == 0 && M_total >= 65536) ? 128 : 0));
+    if (force > 0) return (N % force == 0 || (force == 256 && N % 8 == 0 && N > 256)) ? force : 0;
+    // 256-wide tiles move the fewest LDS / L2 bytes per FLOP (the kernels are power-bound: DESIGN.md section 3); an N
+    // tail is computed on clamped filter rows and masked at the store, so 256 is used whenever the padded columns
+    // cost < 3 % (N = 13 440, 5 760, 7 680, ...); otherwise 192 (N = 1 920) or 128 (the full-resolution VAE convs).
+    const int n256 = (N + 255) / 256 * 256;
+    int bn = 0;
+    if (N % 8 == 0 && (n256 - N) * 100 < 3 * N) bn = 256;
+    else if (N % 192 == 0) bn = 192;
+    else if (N % 128 == 0 && M_total >= 65536) bn = 128;
     if (!bn) return 0;
     // small problems: the 128x128 tiles (2 blocks / CU) fill the 256 CUs better
-    const long long tiles = (long long)((M + BM - 1) / BM) * batch * (N / bn);
+    const long long tiles = (long long)((M + BM - 1) / BM) * batch * ((N + bn - 1) / bn);
     return tiles >= 192 ? bn : 0;
 }
 
