@@ -417,7 +417,10 @@ int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
     return tiles >= 192 ? bn : 0;
 }
 
+int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream);
+
 int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
+    if (variant == 3 && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream);
 #define PF_L(BN_) (conv ? (variant == 2 ? launch<BN_, true, 2>(a, stream) : launch<BN_, true, 1>(a, stream)) \
                         : (variant == 2 ? launch<BN_, false, 2>(a, stream) : (variant ? launch<BN_, false, 1>(a, stream) : launch<BN_, false, 0>(a, stream))))
     switch (bn) {

@@ -15,10 +15,10 @@ def _mk(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
-@pytest.fixture(params=[0, 1, 2])
+@pytest.fixture(params=[0, 1, 2, 3])
 def policy(request):
     from pyflow_hip import ops
-    ops.L.load().pf_gemm_set_variant(request.param)     # 0: barrier per slot, 1: one barrier per K-tile, 2: register-prefetch pipeline
+    ops.L.load().pf_gemm_set_variant(request.param)     # 0: barrier per slot, 1: one barrier per K-tile, 2: register-prefetch pipeline, 3: four waves with 128-row wave tiles
     yield ops.gemm_set_policy
     ops.gemm_set_policy(0)
     ops.L.load().pf_gemm_set_variant(1)

@@ -90,3 +90,11 @@ def test_sp_generate_and_tile_parallel_decode(tmp_path, world):
 def test_vae_context_parallel(tmp_path, world, T):
     """temporal context-parallel VAE decode (halo exchange per causal conv, uneven frame ranges) == single process"""
     _launch(world, "cp_worker.py", [T], tmp_path)
+
+
+def test_rccl_api_on_one_rank():
+    """the torch.distributed calls of the N > 1 path against the real RCCL library (backend nccl, world size 1)"""
+    p = subprocess.run([sys.executable, os.path.join(HERE, "helpers", "nccl_world1.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    print(p.stdout.decode()[-200:])
