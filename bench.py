@@ -94,10 +94,15 @@ class SampledProfiler:
         def wrapped(*a, **k):
             self.prof.enabled = self.active and (self.count % self.period == 0)
             self.count += 1
+            # a sampled forward runs its launches back-to-back on ONE stream, so that each HIP-event pair brackets one
+            # kernel running alone (the side-stream text path would overlap two kernels inside the bracket)
+            keep = eng.overlap_text
+            eng.overlap_text = keep and not self.prof.enabled
             try:
                 return orig(*a, **k)
             finally:
                 self.prof.enabled = False
+                eng.overlap_text = keep
         eng.forward_tokens = wrapped
         self.active = False
 
@@ -224,27 +229,29 @@ def main():
     summ = ops.PROFILER.summary()
     roof = None
     extra = {}
+    recs = {}
     for name, s in summ.items():
         if s["ms_total"] <= 0:
             continue
         tf = s["work_total"] / (s["ms_total"] * 1e-3) / 1e12
-        rec = dict(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                   frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None, kernel=name, launches_timed=s["launches"],
-                   avg_launch_ms=round(s["ms_total"] / s["launches"], 4))
-        if name == "gemm":
-            roof = rec
-            try:     # HBM traffic of the dominant kernel: rocprofv3 --pmc passes committed under profiles/
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
-                    pm = json.load(f)["kernels"]
-                k = next(v for n, v in pm.items() if "gemm256_kernel<192" in n)
-                rec["traffic"] = round(k["hbm_bytes_per_launch"])
-                rec["traffic_note"] = ("bytes per launch of gemm256_kernel<192> = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction), mean "
-                                       "over the launches of a full-width forward at L=15488 (profiles/r01_pmc_forward_maxL.json); "
-                                       "counted at the L2<->fabric interface incl. Infinity-Cache hits")
-            except Exception:
-                pass
-        else:
-            extra[name] = rec
+        recs[name] = dict(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                          frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None, kernel=name, launches_timed=s["launches"],
+                          avg_launch_ms=round(s["ms_total"] / s["launches"], 4), ms_timed=round(s["ms_total"], 1))
+    # dominant kernel = the one with the most device time among the sampled launches (names = rocprofv3 kernel names)
+    dom = max(recs, key=lambda n: recs[n]["ms_timed"]) if recs else None
+    roof = recs.pop(dom) if dom else None
+    extra = recs
+    if roof is not None and roof["kernel"].startswith("gemm256_kernel"):
+        try:     # HBM traffic of that kernel: rocprofv3 --pmc passes committed under profiles/
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
+                pm = json.load(f)["kernels"]
+            k = next(v for n, v in pm.items() if roof["kernel"].split(">")[0] in n)
+            roof["traffic"] = round(k["hbm_bytes_per_launch"])
+            roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
+                                    "the launches of one full-width forward at L=15488 (profiles/r01_pmc_forward_maxL.json); "
+                                    "counted at the L2<->fabric interface incl. Infinity-Cache hits")
+        except Exception:
+            pass
     value = frames_per_video * args.steps * (1 if use_sp else world) / dt
     res = {
         "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling",

@@ -224,6 +224,9 @@ extern "C" int pf_gemm_set_policy(int force) {
     g_gemm256_force = force;
     return 0;
 }
+extern "C" int pf_gemm_which(int M, int batch, int N) {   // tile width pf_gemm_bf16 would use: 0 = 128x128 kernel, else 256xBN
+    return pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
+}
 extern "C" int pf_gemm_set_variant(int v) {     // tuning hook, not part of the documented ABI
     g_gemm256_variant = v;
     return 0;
