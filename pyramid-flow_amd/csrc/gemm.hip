@@ -248,6 +248,11 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
     a.out_scale = 1.f; a.n_valid = d->N;
     if (a.gelu_from % 8) return set_err("pf_gemm_bf16: gelu_from must be a multiple of 8");
+    {
+        static int gmv = -1;
+        if (gmv < 0) { const char* e = getenv("PF_GEMM_GROUPM"); gmv = e ? atoi(e) : 0; }
+        a.group_m = gmv;
+    }
     if (const int bn = bn256) {
         pf_gemm256_launch(a, bn, false, g_gemm256_variant, stream);
         hipError_t e2 = hipGetLastError();

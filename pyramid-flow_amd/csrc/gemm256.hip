@@ -67,10 +67,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
     const int TM = tiles_m * p.batch;
     const int nwg = TM * tiles_n;
     int t = xcd_remap(blockIdx.x, nwg);
-    const int group_sz = GROUP_M * tiles_n;
+    const int GM = p.group_m > 0 ? p.group_m : GROUP_M;
+    const int group_sz = GM * tiles_n;
     const int grp = t / group_sz;
-    const int first_m = grp * GROUP_M;
-    const int gm = min(TM - first_m, GROUP_M);
+    const int first_m = grp * GM;
+    const int gm = min(TM - first_m, GM);
     const int r_in = t - grp * group_sz;
     const int tn = r_in / gm;
     const int tmm = first_m + (r_in - tn * gm);

@@ -32,6 +32,7 @@ struct Args {
     int gate_stride, batch;
     int gelu_from, flags, n_valid;
     float out_scale;
+    int group_m;             // M-tiles per L2 super-tile of the 256-row kernels (tile order; 0 = default)
     ConvGeom cg; OutMap om;
 };
 
