@@ -119,6 +119,35 @@ class PyramidDiTForVideoGeneration:
     def do_classifier_free_guidance(self):
         return self._guidance_scale > 0
 
+    # ---- raw .pth checkpoints (:213-241): same key handling as the reference, then the weights are re-packed
+    @staticmethod
+    def remap_dit_checkpoint(checkpoint):
+        """:213-224: drop `vae*` / `text_encoder*` entries, strip a leading `dit.`"""
+        out = {}
+        for key, val in checkpoint.items():
+            if key.startswith("vae") or key.startswith("text_encoder"):
+                continue
+            out[key.split(".", 1)[1] if key.startswith("dit") else key] = val
+        return out
+
+    def load_checkpoint(self, checkpoint_path, model_key="model", **kwargs):
+        checkpoint = torch.load(checkpoint_path, map_location="cpu")
+        sd = self.remap_dit_checkpoint(checkpoint)
+        cfg = self.dit.cfg
+        self.dit = type(self.dit)(sd, cfg, self._device, **({"comm": self.sp} if self.sp is not None else {}))
+        self.dit.config = type("Cfg", (), dict(cfg))()
+        self._plans = {}
+        print(f"Load checkpoint from {checkpoint_path}: {len(sd)} tensors re-packed")
+
+    def load_vae_checkpoint(self, vae_checkpoint_path, model_key="model"):
+        from .vae import CausalVideoVAE
+        checkpoint = torch.load(vae_checkpoint_path, map_location="cpu")[model_key]
+        sd = {k.split(".", 1)[1]: v for k, v in checkpoint.items() if k.startswith("vae.")}          # :235-239
+        tiling = self.vae.use_tiling if self.vae is not None else False
+        self.vae = CausalVideoVAE(sd, None if self.vae is None else self.vae.cfg_in, self._device)
+        self.vae.enable_tiling(tiling)
+        print(f"Load the VAE from {vae_checkpoint_path}: {len(sd)} tensors re-packed")
+
     def enable_sequential_cpu_offload(self):
         # 288 GB of HBM: offloading is a no-op by design (pipeline.py:201-211 exists to fit 8-12 GB cards)
         self.sequential_offload_enabled = False

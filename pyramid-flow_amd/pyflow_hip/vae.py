@@ -384,6 +384,7 @@ class CausalVideoVAE:
         from . import synth
         self.dev = torch.device(device)
         cfg_in = dict(cfg) if cfg else None
+        self.cfg_in = cfg_in
         cfg = dict(cfg or synth.VAE_DEFAULT)
         if "decoder_block_out_channels" in cfg:      # reference-style config (causal_vae.py:73-116)
             cfg = dict(latent_channels=cfg.get("decoder_in_channels", 4),

@@ -56,3 +56,21 @@ def test_non_prefix_mask_rejected():
     m = torch.tensor([[1, 0, 1, 0]])
     with pytest.raises(NotImplementedError):
         SequencePlan([(1, 4, 4)], m, [16, 24, 24], "cpu")
+
+
+def test_checkpoint_key_remap_and_diffusers_dir(tmp_path):
+    """raw-.pth key handling of load_checkpoint (pipeline.py:213-224) and the diffusers directory loader (:73,156)."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from pyflow_hip.pipeline import PyramidDiTForVideoGeneration as P, _load_diffusers_dir
+    ck = {"dit.proj_out.weight": torch.ones(2, 2), "proj_out.bias": torch.zeros(2), "vae.decoder.x": torch.ones(1),
+          "text_encoder.y": torch.ones(1)}
+    out = P.remap_dit_checkpoint(ck)
+    assert set(out) == {"proj_out.weight", "proj_out.bias"}
+    d = tmp_path / "diffusion_transformer_768p"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"num_layers": 8, "axes_dims_rope": [16, 24, 24]}))
+    save_file({"proj_out.weight": torch.arange(4.0).reshape(2, 2)}, str(d / "diffusion_pytorch_model.safetensors"))
+    sd, cfg = _load_diffusers_dir(str(d))
+    assert cfg["num_layers"] == 8 and torch.equal(sd["proj_out.weight"], torch.arange(4.0).reshape(2, 2))
