@@ -80,6 +80,7 @@ typedef struct {
     int out_t_shift;         /* added to the output frame index, frames < 0 dropped (is_init_image drop, modeling_resnet.py:726) */
     int in_sh, in_sw;        /* input stride per output pixel in h / w (0 = 1): CausalDownsample2x of the encoder
                                 (modeling_resnet.py:291-336) reads X[... (h*in_sh+dh) ... (w*in_sw+dw) ...] */
+    int in_st;               /* input frame stride per output frame (0 = 1): CausalTemporalDownsample2x (:458-502) */
 } pf_conv_desc;
 int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
             const int hw = p.cg.H * p.cg.W;
             const int tt = m / hw, rem = m - tt * hw;
             const int hh = rem / p.cg.W, ww = rem - hh * p.cg.W;
-            asrc[j] = A + p.cg.base_off + (((long long)tt * p.cg.Hp + hh * p.cg.sh) * p.cg.Wp + ww * p.cg.sw) * p.cg.Cin + c * 8;
+            asrc[j] = A + p.cg.base_off + (((long long)tt * p.cg.st * p.cg.Hp + hh * p.cg.sh) * p.cg.Wp + ww * p.cg.sw) * p.cg.Cin + c * 8;
         } else {
             asrc[j] = A + (long long)m * p.lda + c * 8;
         }
@@ -282,7 +282,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     a.gelu_from = d->N; a.flags = d->flags; a.out_scale = d->out_scale == 0.f ? 1.f : d->out_scale;
     a.n_valid = d->n_valid > 0 ? d->n_valid : d->N;
     a.cg = ConvGeom{d->H, d->W_, d->Hp, d->Wp, d->Cin, d->kt, d->kh, d->kw, d->in_base_off,
-                    d->in_sh > 0 ? d->in_sh : 1, d->in_sw > 0 ? d->in_sw : 1};
+                    d->in_sh > 0 ? d->in_sh : 1, d->in_sw > 0 ? d->in_sw : 1, d->in_st > 0 ? d->in_st : 1};
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
     if (const int bn = pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force())) {

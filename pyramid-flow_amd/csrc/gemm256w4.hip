@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const Args p) {
             const int hw = p.cg.H * p.cg.W;
             const int tt = m / hw, rem = m - tt * hw;
             const int hh = rem / p.cg.W, ww = rem - hh * p.cg.W;
-            asrc[j] = A + p.cg.base_off + (((long long)tt * p.cg.Hp + hh * p.cg.sh) * p.cg.Wp + ww * p.cg.sw) * p.cg.Cin + c * 8;
+            asrc[j] = A + p.cg.base_off + (((long long)tt * p.cg.st * p.cg.Hp + hh * p.cg.sh) * p.cg.Wp + ww * p.cg.sw) * p.cg.Cin + c * 8;
         } else {
             asrc[j] = A + (long long)m * p.lda + c * 8;
         }

@@ -11,6 +11,7 @@ struct ConvGeom {            // implicit-GEMM addressing of a channels-last, spa
     int kt, kh, kw;          // taps
     long long base_off;      // element offset of tap (0,0,0) for output pixel (0,0,0)
     int sh, sw;              // input stride per output pixel (strided down-sampling convs of the VAE encoder)
+    int st;                  // input FRAME stride per output frame (CausalTemporalDownsample2x)
 };
 
 struct OutMap {              // where output row m / column-group g lands

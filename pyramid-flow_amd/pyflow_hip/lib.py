@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("Wop", C.c_int), ("Cout_pitch", C.c_int),
                 ("out_base_off", C.c_longlong),
                 ("flags", C.c_int), ("out_scale", C.c_float), ("out_t_shift", C.c_int),
-                ("in_sh", C.c_int), ("in_sw", C.c_int)]
+                ("in_sh", C.c_int), ("in_sw", C.c_int), ("in_st", C.c_int)]
 
 
 class AttnDesc(C.Structure):

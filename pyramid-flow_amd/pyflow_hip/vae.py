@@ -85,7 +85,7 @@ class ConvW:
         self.N, self.n_valid, self.Cg, self.groups, self.cin_p = Np, n_valid, cg, groups, cp
 
 
-def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1):
+def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1, tdown=1):
     """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple.
     down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2."""
     lib = L.load()
@@ -95,8 +95,11 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
     d.X = src.t.data_ptr()
     d.W = cw.w.data_ptr()
     d.bias = cw.b.data_ptr()
+    if tdown > 1:          # causal temporal stride: frames [0, 0, x0 .. x(Tc-1)] -> floor((Tc - 1) / 2) + 1 outputs
+        Tc = (Tc - 1) // tdown + 1
     d.T, d.H, d.W_ = Tc, src.H // down, src.W // down
     d.in_sh = d.in_sw = down
+    d.in_st = tdown
     d.Hp, d.Wp, d.Cin = src.Hp, src.Wp, src.Cp
     d.kt, d.kh, d.kw = cw.kt, cw.kh, cw.kw
     assert cw.cin_p == src.Cp
@@ -137,6 +140,7 @@ class _TileProgram:
         self.vae, self.th, self.tw = vae, th, tw
         self.bufs = {}
         self.dev = vae.dev
+        self.cw = vae.convs         # conv weight set (the clip encoder swaps in the full 3-tap encoder filters)
         cfg = vae.cfg
         # frames per chunk at each temporal level (first chunk / later chunks)
         self.tmax = [max(t_first, t_later)]
@@ -145,6 +149,11 @@ class _TileProgram:
             if up:
                 tf_, tl = 2 * tf_ - 1, 2 * tl
                 self.tmax.append(max(tf_, tl))
+        if encoder:                 # frames per temporal level of the encoder: T -> (T - 1) // 2 + 1 per temporal downsample
+            for dn in vae.enc_cfg["temporal_down_sample"]:
+                if dn:
+                    tf_ = (tf_ - 1) // 2 + 1
+                    self.tmax.append(tf_)
         self.stats = torch.zeros(max(self.tmax) * 512 * 2, dtype=torch.float64, device=self.dev)
         n = th * tw
         ca = vae.attn_pitch
@@ -199,20 +208,20 @@ class _TileProgram:
         n1 = self.buf(p + "n1", lvl, x.H, x.W, x.C)
         self.gn(x, n1, p + "norm1")
         h = self.buf(p + "h", lvl, x.H, x.W, cout)
-        conv(n1, h, v.convs[p + "conv1"], Tc)
+        conv(n1, h, self.cw[p + "conv1"], Tc)
         n1.shift_cache()
         n2 = self.buf(p + "n2", lvl, x.H, x.W, cout)
         self.gn(h, n2, p + "norm2")
         res = x
-        if (p + "conv_shortcut") in v.convs:
+        if (p + "conv_shortcut") in self.cw:
             res = self.buf(p + "sc", lvl, x.H, x.W, cout)
-            conv(x, res, v.convs[p + "conv_shortcut"], Tc)
+            conv(x, res, self.cw[p + "conv_shortcut"], Tc)
         out = self.buf(out_name, lvl, x.H, x.W, cout)
-        conv(n2, out, v.convs[p + "conv2"], Tc, res=res)
+        conv(n2, out, self.cw[p + "conv2"], Tc, res=res)
         n2.shift_cache()
         return out
 
-    def mid_attention(self, x, out_name, side="decoder"):
+    def mid_attention(self, x, out_name, side="decoder", lvl=0):
         """per-frame 1-head attention (modeling_block.py:456-460 + diffusers Attention, deprecated-attn-block form)."""
         v = self.vae
         Tc, n, npad, ca = x.cur, self.n_tok, self.npad, v.attn_pitch
@@ -224,7 +233,7 @@ class _TileProgram:
         wo, bo = attn["to_out.0"]
         ops.gemm(self.a_x, wq, self.a_q, npad, ca, ca, ca, ca, ca, bias=bq, batch=Tc, strideA=npad * ca, strideC=npad * ca)
         ops.gemm(self.a_x, wk, self.a_k, npad, ca, ca, ca, ca, ca, bias=bk, batch=Tc, strideA=npad * ca, strideC=npad * ca)
-        out = self.buf(out_name, 0, x.H, x.W, x.C)
+        out = self.buf(out_name, lvl, x.H, x.W, x.C)
         for f in range(Tc):
             fo = f * npad * ca
             # V^T = Wv . X^T  (bias folded into the PV epilogue: rows of P sum to 1)
@@ -304,47 +313,52 @@ class _TileProgram:
         return nf
 
 
-    # ---- one FRAME through encoder + quant_conv (modeling_enc_dec.py:154-198) ---------------------------------------
-    def run_encoder_frame(self, img, h0, w0, out_tile):
-        """img [3,1,H,W] fp32 in [-1,1]; the window (h0, w0, 8*th, 8*tw) -> moments tile [1][th][tw][64] bf16.
-        A single frame sees two zero frames in front of every causal conv (modeling_causal_conv.py:116-146), so each
-        3x3x3 filter reduces to its last temporal tap: the filters are packed as kt = 1 (CausalVideoVAE.__init__)."""
+    # ---- a frame or a clip through encoder + quant_conv (modeling_enc_dec.py:154-198), un-chunked ---------------------
+    def run_encoder(self, img, h0, w0, out_tile):
+        """img [3,T,H,W] fp32 in [-1,1]; the window (h0, w0, 8*th, 8*tw) -> moments tile [T'][th][tw][64] bf16.
+        T = 1 (image-to-video): a single frame sees two zero frames in front of every causal conv
+        (modeling_causal_conv.py:116-146), so each 3x3x3 filter reduces to its last temporal tap and the filters are
+        packed as kt = 1.  T > 1: the full filters over [0, 0, x0 ..] with the temporal stride-2 downsamplers."""
         v = self.vae
         ecfg = v.enc_cfg
+        T = img.shape[1]
         s_ = 2 ** sum(ecfg["spatial_down_sample"])
         ph, pw = self.th * s_, self.tw * s_
         xin = self.buf("e.img", 0, ph, pw, 3)
         lib = L.load()
         Zc, ZT, ZH, ZW = img.shape
         check(lib.pf_latent_to_nhwc(C.c_void_p(img.data_ptr()), C.c_void_p(xin.t.data_ptr()), C.c_int(Zc), C.c_int(ZT),
-                                    C.c_int(ZH), C.c_int(ZW), C.c_int(0), C.c_int(1), C.c_int(h0), C.c_int(w0),
+                                    C.c_int(ZH), C.c_int(ZW), C.c_int(0), C.c_int(T), C.c_int(h0), C.c_int(w0),
                                     C.c_int(ph), C.c_int(pw), C.c_int(xin.Cp), C.c_int(xin.Hp), C.c_int(xin.Wp),
                                     C.c_longlong(xin.fs), C.c_longlong(xin.off(2)), C.c_float(1.0), C.c_float(0.0),
                                     C.c_float(1.0), C.c_float(0.0), stream()))
-        xin.cur = 1
+        xin.cur = T
         boc = ecfg["block_out_channels"]
+        lvl = 0
         x = self.buf("e.conv_in", 0, ph, pw, boc[0])
-        conv(xin, x, v.convs["encoder.conv_in"], 1)
+        conv(xin, x, self.cw["encoder.conv_in"], T)
         for i, co in enumerate(boc):
             p = f"encoder.down_blocks.{i}."
             for j in range(ecfg["layers_per_block"][i]):
-                x = self.resnet(x, p + f"resnets.{j}.", 0, f"e.d{i}.r{j}", co)
+                x = self.resnet(x, p + f"resnets.{j}.", lvl, f"e.d{i}.r{j}", co)
             if ecfg["spatial_down_sample"][i]:
-                y = self.buf(f"e.d{i}.sp", 0, x.H // 2, x.W // 2, co)
-                conv(x, y, v.convs[p + "downsamplers.0.conv"], 1, down=2)
+                y = self.buf(f"e.d{i}.sp", lvl, x.H // 2, x.W // 2, co)
+                conv(x, y, self.cw[p + "downsamplers.0.conv"], x.cur, down=2)
                 x = y
-            if ecfg["temporal_down_sample"][i]:        # T = 1: stride-2 temporal conv of [0, 0, x] -> one frame
-                y = self.buf(f"e.d{i}.tp", 0, x.H, x.W, co)
-                conv(x, y, v.convs[p + "temporal_downsamplers.0.conv"], 1)
+            if ecfg["temporal_down_sample"][i]:
+                y = self.buf(f"e.d{i}.tp", lvl + 1, x.H, x.W, co)
+                conv(x, y, self.cw[p + "temporal_downsamplers.0.conv"], x.cur, tdown=2 if T > 1 else 1)
                 x = y
-        x = self.resnet(x, "encoder.mid_block.resnets.0.", 0, "e.mid.r0", boc[-1])
-        x = self.mid_attention(x, "e.mid.attn", side="encoder")
-        x = self.resnet(x, "encoder.mid_block.resnets.1.", 0, "e.mid.r1", boc[-1])
-        n = self.buf("e.norm_out", 0, x.H, x.W, x.C)
+                lvl += 1
+        x = self.resnet(x, "encoder.mid_block.resnets.0.", lvl, "e.mid.r0", boc[-1])
+        x = self.mid_attention(x, "e.mid.attn", side="encoder", lvl=lvl)
+        x = self.resnet(x, "encoder.mid_block.resnets.1.", lvl, "e.mid.r1", boc[-1])
+        n = self.buf("e.norm_out", lvl, x.H, x.W, x.C)
         self.gn(x, n, "encoder.conv_norm_out")
-        m = self.buf("e.moments", 0, x.H, x.W, 2 * ecfg["latent_channels"])
-        conv(n, m, v.convs["encoder.conv_out"], 1)
-        conv(m, None, v.convs["quant_conv"], 1, dst_raw=(out_tile, x.H, x.W, out_tile.shape[-1], 0))
+        m = self.buf("e.moments", lvl, x.H, x.W, 2 * ecfg["latent_channels"])
+        conv(n, m, self.cw["encoder.conv_out"], n.cur)
+        conv(m, None, self.cw["quant_conv"], m.cur, dst_raw=(out_tile, x.H, x.W, out_tile.shape[-1], 0))
+        return m.cur
 
 
 class DiagonalGaussianDistribution:
@@ -409,12 +423,14 @@ class CausalVideoVAE:
                                 spatial_down_sample=tuple(ref_cfg.get("encoder_spatial_down_sample", (True, True, True, False))),
                                 temporal_down_sample=tuple(ref_cfg.get("encoder_temporal_down_sample", (True, True, True, False))))
         self.convs, self.norms, self.attn, self.enc_attn = {}, {}, {}, {}
+        self._enc_full, self.convs_clip = {}, None
         for k in sd:
             if k.endswith(".conv.weight"):
                 name = k[:-len(".conv.weight")]
                 groups = 4 if ".upsamplers." in name else (2 if ".temporal_upsamplers." in name else 1)
                 wt = sd[k]
                 if name.startswith(("encoder.", "quant_conv")) and wt.shape[2] == 3:
+                    self._enc_full[name] = (wt, sd[name + ".conv.bias"])        # packed on the first clip encode
                     wt = wt[:, :, 2:3]          # single-frame encode: only the last temporal tap meets data
                 self.convs[name] = ConvW(wt, sd[name + ".conv.bias"], self.dev, groups)
             elif k.endswith(".weight") and sd[k].ndim == 1:
@@ -695,20 +711,31 @@ class CausalVideoVAE:
 
     @torch.no_grad()
     def encode(self, x, return_dict=True, is_init_image=True, temporal_chunk=False, window_size=16, tile_sample_min_size=256):
-        """modeling_causal_vae.py:274-308 / tiled_encode :409-466 for ONE frame (what generate_i2v encodes,
-        pyramid_dit_for_video_gen_pipeline.py:906-911): x [1,3,1,H,W] in [-1,1] -> latent_dist over [1,C,1,H/8,W/8].
-        Multi-frame (chunked) video encode is the next scope row."""
+        """modeling_causal_vae.py:274-308 / tiled_encode :409-466: x [1,3,T,H,W] in [-1,1] -> latent_dist over
+        [1,C,T',H/8,W/8] (T' = 1 + (T-1)/8).  T = 1 is what generate_i2v encodes (pyramid_dit_for_video_gen_pipeline.py:
+        906-911); clips run in one causal pass (temporal_chunk=False, the default); the sliding-window chunk_encode of
+        long videos (:310-341) is not implemented."""
         if not self.has_encoder:
             raise RuntimeError("this CausalVideoVAE was built without encoder weights")
         assert x.shape[0] == 1 and x.shape[1] == 3
-        if x.shape[2] != 1:
-            raise NotImplementedError("encode() handles a single frame (image-to-video conditioning); video clips: next round")
+        T = x.shape[2]
+        if temporal_chunk:
+            raise NotImplementedError("chunk_encode (sliding-window encode of long clips, modeling_causal_vae.py:310-341) "
+                                      "is not implemented: encode() processes the clip in one causal pass")
         img = x[0].to(self.dev, torch.float32).contiguous()
         _, _, H, W = img.shape
         s_ = self.downsample_scale
         lat = self.enc_cfg["latent_channels"]
         ts = tile_sample_min_size
         lib = L.load()
+        Tl = T
+        for dn in self.enc_cfg["temporal_down_sample"]:
+            if dn:
+                Tl = (Tl - 1) // 2 + 1
+        if T > 1 and self.convs_clip is None:      # full 3-tap encoder filters, packed once
+            self.convs_clip = dict(self.convs)
+            for name, (wt, bs) in self._enc_full.items():
+                self.convs_clip[name] = ConvW(wt, bs, self.dev, 1)
         tiled = self.use_tiling and (W > ts or H > ts)
         if not tiled:
             tiles, i_list, j_list = None, [0], [0]
@@ -721,21 +748,24 @@ class CausalVideoVAE:
             for j in j_list:
                 ph, pw = (min(ts, H - i), min(ts, W - j)) if tiled else (H, W)
                 assert ph % s_ == 0 and pw % s_ == 0
-                key = ("enc", ph // s_, pw // s_)
+                key = ("enc", ph // s_, pw // s_, T)
                 prog = self._programs.get(key)
                 if prog is None:
-                    prog = _TileProgram(self, ph // s_, pw // s_, 1, 1, encoder=True)
+                    prog = _TileProgram(self, ph // s_, pw // s_, T, T, encoder=True)
+                    if T > 1:
+                        prog.cw = self.convs_clip
                     self._programs[key] = prog
                 prog.reset()
-                t = torch.empty(1, ph // s_, pw // s_, 64, dtype=torch.bfloat16, device=self.dev)
-                prog.run_encoder_frame(img, i, j, t)
+                t = torch.empty(Tl, ph // s_, pw // s_, 64, dtype=torch.bfloat16, device=self.dev)
+                got = prog.run_encoder(img, i, j, t)
+                assert got == Tl, (got, Tl)
                 row.append(t)
             rows.append(row)
         h, w = H // s_, W // s_
-        moments = torch.empty(2 * lat, 1, h, w, dtype=torch.float32, device=self.dev)
+        moments = torch.empty(2 * lat, Tl, h, w, dtype=torch.float32, device=self.dev)
         if not tiled:
             t = rows[0][0]
-            check(lib.pf_nhwc_to_planar_f32(C.c_void_p(t.data_ptr()), C.c_void_p(moments.data_ptr()), C.c_int(1), C.c_int(h),
+            check(lib.pf_nhwc_to_planar_f32(C.c_void_p(t.data_ptr()), C.c_void_p(moments.data_ptr()), C.c_int(Tl), C.c_int(h),
                                             C.c_int(w), C.c_int(64), C.c_int(2 * lat), C.c_int(h), C.c_int(w), C.c_int(h),
                                             C.c_int(w), C.c_int(0), C.c_int(0), stream()))
         else:
@@ -751,7 +781,7 @@ class CausalVideoVAE:
                     if j > 0:
                         self._blend(row[j - 1], t, blend, False, cp=64)
                     ch_, cw_ = min(t.shape[1], limit), min(t.shape[2], limit)
-                    check(lib.pf_nhwc_to_planar_f32(C.c_void_p(t.data_ptr()), C.c_void_p(moments.data_ptr()), C.c_int(1),
+                    check(lib.pf_nhwc_to_planar_f32(C.c_void_p(t.data_ptr()), C.c_void_p(moments.data_ptr()), C.c_int(Tl),
                                                     C.c_int(t.shape[1]), C.c_int(t.shape[2]), C.c_int(64), C.c_int(2 * lat),
                                                     C.c_int(ch_), C.c_int(cw_), C.c_int(h), C.c_int(w), C.c_int(y0), C.c_int(x0),
                                                     stream()))

@@ -81,3 +81,28 @@ def test_generate_i2v_vs_reference_fixture():
                                video_guidance_scale=g["video_guidance"], generator=torch.Generator().manual_seed(g["latent_seed"]),
                                output_type="uint8", posterior_noise=g["posterior_eps"])
     assert frames.shape == (1 + 8 * (g["temp"] - 1), 64, 128, 3) and frames.dtype == torch.uint8
+
+
+@pytest.mark.parametrize("T", [9, 17])
+def test_clip_encode_vs_oracle(T):
+    """multi-frame encode in one causal pass (temporal stride-2 downsamplers, full 3-tap filters), plain and tiled"""
+    from pyflow_hip.vae import CausalVideoVAE
+    from oracle.vae_oracle import vae_encode_moments
+    g = torch.load(GOLD)
+    sd = _vae_sd(g)
+    vae = CausalVideoVAE(sd, _vae_cfg(g), "cuda")
+    x = torch.randn(1, 3, T, 32, 48, generator=torch.Generator().manual_seed(8)).clamp(-1, 1)
+    ocfg = {k: g["vae_enc_cfg"][k] for k in ("encoder_block_out_channels", "encoder_layers_per_block",
+                                              "encoder_spatial_down_sample", "encoder_temporal_down_sample")}
+    ref = vae_encode_moments(sd, ocfg, x)
+    post = vae.encode(x.cuda()).latent_dist
+    assert post.parameters.shape == ref.shape == (1, 32, 1 + (T - 1) // 8, 4, 6)
+    assert rel_l2(post.parameters.float().cpu(), ref) < 3e-2
+    vae.enable_tiling()
+    ref_t = vae_encode_moments(sd, ocfg, x, use_tiling=True, tile_sample_min_size=32)
+    post_t = vae.encode(x.cuda(), tile_sample_min_size=32).latent_dist
+    assert rel_l2(post_t.parameters.float().cpu(), ref_t) < 3e-2
+    # the single-frame fast path (last temporal tap only) agrees with the general path on a 1-frame clip
+    one = vae.encode(x[:, :, :1].cuda(), tile_sample_min_size=32).latent_dist.parameters
+    ref1 = vae_encode_moments(sd, ocfg, x[:, :, :1], use_tiling=True, tile_sample_min_size=32)
+    assert rel_l2(one.float().cpu(), ref1) < 3e-2
