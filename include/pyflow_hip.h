@@ -38,6 +38,8 @@ int pf_version(void);
  * Constraints: N % 128 == 0, K % 64 == 0, lda/ldw/ldc % 8 == 0.  M arbitrary. */
 #define PF_GEMM_GATE_RES 1
 #define PF_GEMM_OUT_F32 2
+#define PF_GEMM_ACT_QUICK_GELU 4 /* the gelu_from columns get x*sigmoid(1.702x) instead (CLIP-L MLP, transformers activations.py) */
+#define PF_GEMM_ACT_GELU_ERF 8   /* ... or the exact erf GELU (CLIP-G MLP) */
 typedef struct {
     const void* A; const void* W; void* C;
     const float* bias;      /* [N] or NULL */
@@ -188,6 +190,35 @@ int pf_blend_tiles(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb
  * (pipeline.py:1238-1239) */
 int pf_to_uint8(const void* tile, void* out, int T, int Ht, int Wt, int Cp, int crop_h, int crop_w, int H, int W,
                 int y0, int x0, pf_stream_t stream);
+
+
+/* ------------------------------------------------------------------ prompt encoders --------------
+ * The step before the sampling path: FluxTextEncoderWithMask (pyramid_dit/flux_modules/modeling_text_encoder.py:15-134)
+ * and SD3TextEncoderWithMask (pyramid_dit/mmdit_modules/modeling_text_encoder.py:15-139) call transformers'
+ * T5EncoderModel and CLIPTextModel(WithProjection) (requirements.txt pins transformers==4.39.3).  Linear layers use
+ * pf_gemm_bf16 (CLIP MLP activation via PF_GEMM_ACT_*), CLIP's affine LayerNorm is pf_ln_modulate with
+ * shift = beta, scale = gamma - 1.
+ * pf_embed_rows: out[r][0:D] = table[ids[r]] (+ pos[r % L])   (T5 `shared` / CLIP token+position embedding);
+ *   ids are clamped to [0, vocab). */
+int pf_embed_rows(const void* table, const int* ids, const void* pos /* NULL = none */, void* out, int D, int n, int L,
+                  int ldo, int vocab, pf_stream_t stream);
+/* pf_rmsnorm: T5LayerNorm  y = x * rsqrt(mean(x^2) + eps) * w  (fp32 math, one rounding), D <= 4096 */
+int pf_rmsnorm(const void* x, void* y, const float* w, int D, int rows, int ldx, int ldy, float eps, pf_stream_t stream);
+/* pf_glu_mul: y[r][c] = x[r][c] * x[r][F + c], c < F   (T5DenseGatedActDense: hidden_gelu * hidden_linear) */
+int pf_glu_mul(const void* x, void* y, int rows, int F, int ldx, int ldy, pf_stream_t stream);
+/* pf_attention_small_bf16: O = softmax(Q K^T * scale + bias[h] + masks) V, head_dim 64, L <= 256, token-major Q/K/V/O
+ *   (head h at column h*64).  bias: fp32 [H][L][L] additive (T5 relative-position bias) or NULL; key_mask: int [B][L],
+ *   0 = padded key excluded (T5 attention_mask) or NULL; causal: key j > query i excluded (CLIP).  A row with no visible
+ *   key gets zeros. */
+typedef struct {
+    const void* Q; const void* K; const void* V; void* O;
+    int ldq, ldk, ldv, ldo;
+    long long strideQ, strideK, strideV, strideO; /* per batch entry */
+    int B, H, L;
+    const float* bias; const int* key_mask;
+    int causal; float scale;
+} pf_attn_small_desc;
+int pf_attention_small_bf16(const pf_attn_small_desc* d, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

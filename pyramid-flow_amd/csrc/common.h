@@ -52,6 +52,25 @@ PF_DEVICE float gelu_tanh(float x) {
     return x / (1.0f + __expf(-2.0f * u));
 }
 
+// CLIP text towers: quick_gelu = x * sigmoid(1.702 x) (CLIP-L), exact erf GELU (CLIP-G); transformers activations.py
+PF_DEVICE float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+PF_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// activation of the GEMM epilogue: GELU-tanh unless PF_GEMM_ACT_QUICK_GELU (4) / PF_GEMM_ACT_GELU_ERF (8) is set
+PF_DEVICE void act8(float* v, int flags) {
+    if (flags & 12) {
+        if (flags & 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = quick_gelu(v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+    }
+}
+
 PF_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): gives each XCD a

@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bias[e]; v[4 + e] = v1[e] + bias[4 + e]; }
         if (do_gelu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+            act8(v, p.flags);
         }
         long long coff;
         if (CONV && p.om.mode == 1) {

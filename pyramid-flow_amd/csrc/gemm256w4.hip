@@ -223,8 +223,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const Args p) {
                 for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
             }
             if (n >= p.gelu_from) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                act8(v, p.flags);
             }
             long long coff;
             if (CONV && p.om.mode == 1) {

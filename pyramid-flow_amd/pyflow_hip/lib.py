@@ -47,8 +47,19 @@ class AttnDesc(C.Structure):
                 ("scale", C.c_float), ("head_stride_qk", C.c_int), ("q_row_begin", C.c_int), ("q_prescaled", C.c_int)]
 
 
+class AttnSmallDesc(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+                ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
+                ("strideQ", C.c_longlong), ("strideK", C.c_longlong), ("strideV", C.c_longlong),
+                ("strideO", C.c_longlong),
+                ("B", C.c_int), ("H", C.c_int), ("L", C.c_int),
+                ("bias", C.c_void_p), ("key_mask", C.c_void_p), ("causal", C.c_int), ("scale", C.c_float)]
+
+
 GEMM_GATE_RES = 1
 GEMM_OUT_F32 = 2
+GEMM_ACT_QUICK_GELU = 4
+GEMM_ACT_GELU_ERF = 8
 
 # every symbol include/pyflow_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -56,6 +67,7 @@ EXPORTS = [
     "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
     "pf_copy_rows", "pf_sp_relayout", "pf_renoise_upsample", "pf_avgpool2",
     "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",
+    "pf_embed_rows", "pf_rmsnorm", "pf_glu_mul", "pf_attention_small_bf16",
 ]
 
 

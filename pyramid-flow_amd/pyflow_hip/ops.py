@@ -7,7 +7,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import GemmDesc, AttnDesc, ConvDesc, check, ptr, stream, GEMM_GATE_RES, GEMM_OUT_F32  # noqa: F401
+from .lib import (GemmDesc, AttnDesc, AttnSmallDesc, ConvDesc, check, ptr, stream, GEMM_GATE_RES,  # noqa: F401
+                  GEMM_OUT_F32, GEMM_ACT_QUICK_GELU, GEMM_ACT_GELU_ERF)
 
 
 class KernelProfiler:
@@ -177,3 +178,44 @@ def avgpool2(xin, xout, planes, H, W, mul=1.0, round_bf16=False):
     lib = L.load()
     check(lib.pf_avgpool2(ptr(xin), ptr(xout), C.c_longlong(planes), C.c_int(H), C.c_int(W), C.c_float(mul),
                           C.c_int(int(round_bf16)), stream()))
+
+
+# ---------------------------------------------------------------------------------------------- prompt encoders
+def embed_rows(table, ids, out, D, n, vocab, pos=None, Lseq=0, ldo=None):
+    """out[r] = table[ids[r]] (+ pos[r % Lseq]); ids int32 device tensor."""
+    lib = L.load()
+    check(lib.pf_embed_rows(ptr(table), ptr(ids), ptr(pos), ptr(out), C.c_int(D), C.c_int(n), C.c_int(Lseq),
+                            C.c_int(D if ldo is None else ldo), C.c_int(vocab), stream()))
+
+
+def rmsnorm(x, y, w, D, rows, ldx=None, ldy=None, eps=1e-6):
+    lib = L.load()
+    check(lib.pf_rmsnorm(ptr(x), ptr(y), ptr(w), C.c_int(D), C.c_int(rows), C.c_int(D if ldx is None else ldx),
+                         C.c_int(D if ldy is None else ldy), C.c_float(eps), stream()))
+
+
+def glu_mul(x, y, rows, F, ldx=None, ldy=None):
+    lib = L.load()
+    check(lib.pf_glu_mul(ptr(x), ptr(y), C.c_int(rows), C.c_int(F), C.c_int(2 * F if ldx is None else ldx),
+                         C.c_int(F if ldy is None else ldy), stream()))
+
+
+def attention_small(qkv, O, q_off, k_off, v_off, ld, ldo, B, H, Lseq, scale, bias=None, key_mask=None, causal=False):
+    """Q/K/V are column blocks (element offsets q_off/k_off/v_off) of one fused projection buffer [B*Lseq][ld]."""
+    lib = L.load()
+    d = AttnSmallDesc()
+    d.Q = qkv.data_ptr() + 2 * q_off
+    d.K = qkv.data_ptr() + 2 * k_off
+    d.V = qkv.data_ptr() + 2 * v_off
+    d.O = O.data_ptr()
+    d.ldq = d.ldk = d.ldv = ld
+    d.ldo = ldo
+    d.strideQ = d.strideK = d.strideV = Lseq * ld
+    d.strideO = Lseq * ldo
+    d.B, d.H, d.L = B, H, Lseq
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.key_mask = key_mask.data_ptr() if key_mask is not None else None
+    d.causal = int(causal)
+    d.scale = scale
+    PROFILER.launch("attention_small", 4.0 * B * H * Lseq * Lseq * 64,
+                    lambda: check(lib.pf_attention_small_bf16(C.byref(d), stream())))

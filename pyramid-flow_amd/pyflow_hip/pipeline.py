@@ -75,6 +75,11 @@ class PyramidDiTForVideoGeneration:
         self.dit.config = type("Cfg", (), dict(dit_config))()
         self.text_encoder = text_encoder
         self.load_text_encoder = load_text_encoder
+        if text_encoder is None and load_text_encoder and model_path is not None \
+                and os.path.isdir(os.path.join(model_path, "text_encoder")):                   # pipeline.py:99-103, 120-123
+            from .text_encoder import FluxTextEncoderWithMask, SD3TextEncoderWithMask
+            cls = FluxTextEncoderWithMask if model_name == "pyramid_flux" else SD3TextEncoderWithMask
+            self.text_encoder = cls(model_path, device=device)
         self.vae = None
         self.load_vae = load_vae
         if load_vae:
