@@ -85,9 +85,12 @@ class ConvW:
         self.N, self.n_valid, self.Cg, self.groups, self.cin_p = Np, n_valid, cg, groups, cp
 
 
-def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1, tdown=1):
+def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1, tdown=1, later_chunk=False):
     """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple.
-    down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2."""
+    down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2.
+    tdown = 2: CausalTemporalDownsample2x (:458-502).  First chunk / whole clip: windows start at the first cache slot
+    (two zero frames in front).  later_chunk: only ONE frame of context (modeling_causal_conv.py:139-140), i.e. the
+    windows start at the second cache slot and an even chunk of Tc frames gives Tc / 2 outputs."""
     lib = L.load()
     if cw.kt == 3 and src.halo is not None:
         src.exchange_halo()
@@ -95,8 +98,13 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
     d.X = src.t.data_ptr()
     d.W = cw.w.data_ptr()
     d.bias = cw.b.data_ptr()
+    slot_shift = 0
     if tdown > 1:          # causal temporal stride: frames [0, 0, x0 .. x(Tc-1)] -> floor((Tc - 1) / 2) + 1 outputs
-        Tc = (Tc - 1) // tdown + 1
+        if later_chunk:
+            assert Tc % tdown == 0, "later chunks of a strided temporal conv must hold an even number of frames"
+            Tc, slot_shift = Tc // tdown, 1
+        else:
+            Tc = (Tc - 1) // tdown + 1
     d.T, d.H, d.W_ = Tc, src.H // down, src.W // down
     d.in_sh = d.in_sw = down
     d.in_st = tdown
@@ -105,7 +113,7 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
     assert cw.cin_p == src.Cp
     # first temporal slot the taps touch (kt = 3: the two cache slots + the frame; kt = 1: the frame itself) and, for
     # spatial taps, the padded origin (row -1, col -1) instead of the first interior pixel
-    slot0 = 2 - (cw.kt - 1)
+    slot0 = 2 - (cw.kt - 1) + slot_shift
     d.in_base_off = slot0 * src.fs + ((src.Wp + 1) * src.Cp if cw.kh == 1 else 0)
     d.N, d.n_valid = cw.N, cw.n_valid
     d.st, d.sh, d.sw, d.Cg = st, sh, sw, cw.Cg
@@ -314,29 +322,38 @@ class _TileProgram:
 
 
     # ---- a frame or a clip through encoder + quant_conv (modeling_enc_dec.py:154-198), un-chunked ---------------------
-    def run_encoder(self, img, h0, w0, out_tile):
-        """img [3,T,H,W] fp32 in [-1,1]; the window (h0, w0, 8*th, 8*tw) -> moments tile [T'][th][tw][64] bf16.
+    def run_encoder(self, img, h0, w0, out_tile, t0=0, nt=None, chunked=False, first=True, out_frame0=0):
+        """img [3,T,H,W] fp32 in [-1,1]; frames [t0, t0+nt) of the window (h0, w0, 8*th, 8*tw) -> moments tile
+        [T'][th][tw][64] bf16 from frame `out_frame0` on.
         T = 1 (image-to-video): a single frame sees two zero frames in front of every causal conv
         (modeling_causal_conv.py:116-146), so each 3x3x3 filter reduces to its last temporal tap and the filters are
-        packed as kt = 1.  T > 1: the full filters over [0, 0, x0 ..] with the temporal stride-2 downsamplers."""
+        packed as kt = 1.  T > 1: the full filters over [0, 0, x0 ..] with the temporal stride-2 downsamplers.
+        chunked (chunk_encode, modeling_causal_vae.py:310-341): the two previous input frames of every 3-tap conv stay
+        in the cache slots between calls (cache_front_feat, causal_conv.py:128-143); `first` = the chunk that starts
+        the clip."""
         v = self.vae
         ecfg = v.enc_cfg
-        T = img.shape[1]
+        T = img.shape[1] if nt is None else nt
+        whole = img.shape[1]
+        later = chunked and not first
         s_ = 2 ** sum(ecfg["spatial_down_sample"])
         ph, pw = self.th * s_, self.tw * s_
         xin = self.buf("e.img", 0, ph, pw, 3)
         lib = L.load()
         Zc, ZT, ZH, ZW = img.shape
         check(lib.pf_latent_to_nhwc(C.c_void_p(img.data_ptr()), C.c_void_p(xin.t.data_ptr()), C.c_int(Zc), C.c_int(ZT),
-                                    C.c_int(ZH), C.c_int(ZW), C.c_int(0), C.c_int(T), C.c_int(h0), C.c_int(w0),
+                                    C.c_int(ZH), C.c_int(ZW), C.c_int(t0), C.c_int(T), C.c_int(h0), C.c_int(w0),
                                     C.c_int(ph), C.c_int(pw), C.c_int(xin.Cp), C.c_int(xin.Hp), C.c_int(xin.Wp),
                                     C.c_longlong(xin.fs), C.c_longlong(xin.off(2)), C.c_float(1.0), C.c_float(0.0),
                                     C.c_float(1.0), C.c_float(0.0), stream()))
         xin.cur = T
+        self.chunked = chunked
         boc = ecfg["block_out_channels"]
         lvl = 0
         x = self.buf("e.conv_in", 0, ph, pw, boc[0])
         conv(xin, x, self.cw["encoder.conv_in"], T)
+        if chunked:
+            xin.shift_cache()
         for i, co in enumerate(boc):
             p = f"encoder.down_blocks.{i}."
             for j in range(ecfg["layers_per_block"][i]):
@@ -344,10 +361,14 @@ class _TileProgram:
             if ecfg["spatial_down_sample"][i]:
                 y = self.buf(f"e.d{i}.sp", lvl, x.H // 2, x.W // 2, co)
                 conv(x, y, self.cw[p + "downsamplers.0.conv"], x.cur, down=2)
+                if chunked:
+                    x.shift_cache()
                 x = y
             if ecfg["temporal_down_sample"][i]:
                 y = self.buf(f"e.d{i}.tp", lvl + 1, x.H, x.W, co)
-                conv(x, y, self.cw[p + "temporal_downsamplers.0.conv"], x.cur, tdown=2 if T > 1 else 1)
+                conv(x, y, self.cw[p + "temporal_downsamplers.0.conv"], x.cur, tdown=2 if whole > 1 else 1, later_chunk=later)
+                if chunked:
+                    x.shift_cache()
                 x = y
                 lvl += 1
         x = self.resnet(x, "encoder.mid_block.resnets.0.", lvl, "e.mid.r0", boc[-1])
@@ -357,7 +378,9 @@ class _TileProgram:
         self.gn(x, n, "encoder.conv_norm_out")
         m = self.buf("e.moments", lvl, x.H, x.W, 2 * ecfg["latent_channels"])
         conv(n, m, self.cw["encoder.conv_out"], n.cur)
-        conv(m, None, self.cw["quant_conv"], m.cur, dst_raw=(out_tile, x.H, x.W, out_tile.shape[-1], 0))
+        if chunked:
+            n.shift_cache()
+        conv(m, None, self.cw["quant_conv"], m.cur, dst_raw=(out_tile, x.H, x.W, out_tile.shape[-1], out_frame0))
         return m.cur
 
 
@@ -713,15 +736,24 @@ class CausalVideoVAE:
     def encode(self, x, return_dict=True, is_init_image=True, temporal_chunk=False, window_size=16, tile_sample_min_size=256):
         """modeling_causal_vae.py:274-308 / tiled_encode :409-466: x [1,3,T,H,W] in [-1,1] -> latent_dist over
         [1,C,T',H/8,W/8] (T' = 1 + (T-1)/8).  T = 1 is what generate_i2v encodes (pyramid_dit_for_video_gen_pipeline.py:
-        906-911); clips run in one causal pass (temporal_chunk=False, the default); the sliding-window chunk_encode of
-        long videos (:310-341) is not implemented."""
+        906-911); clips run in one causal pass (temporal_chunk=False, the default) or, with temporal_chunk=True, through
+        the sliding window of chunk_encode (:310-341): window_size + 1 frames first, then window_size frames per call,
+        the two previous input frames of every temporal conv kept in its cache slots -- bounded activation memory for
+        long clips, same result as the single pass."""
         if not self.has_encoder:
             raise RuntimeError("this CausalVideoVAE was built without encoder weights")
         assert x.shape[0] == 1 and x.shape[1] == 3
         T = x.shape[2]
-        if temporal_chunk:
-            raise NotImplementedError("chunk_encode (sliding-window encode of long clips, modeling_causal_vae.py:310-341) "
-                                      "is not implemented: encode() processes the clip in one causal pass")
+        chunks = [(0, T)]
+        if temporal_chunk and T > window_size + 1:
+            assert (T - 1) % self.downsample_scale == 0                                   # :314
+            td = 2 ** sum(self.enc_cfg["temporal_down_sample"])
+            assert window_size % td == 0, "window_size must be a multiple of the temporal downsample factor"
+            chunks, fid = [(0, window_size + 1)], window_size + 1
+            while fid < T:
+                chunks.append((fid, min(window_size, T - fid)))
+                fid += window_size
+        chunked = len(chunks) > 1
         img = x[0].to(self.dev, torch.float32).contiguous()
         _, _, H, W = img.shape
         s_ = self.downsample_scale
@@ -748,16 +780,19 @@ class CausalVideoVAE:
             for j in j_list:
                 ph, pw = (min(ts, H - i), min(ts, W - j)) if tiled else (H, W)
                 assert ph % s_ == 0 and pw % s_ == 0
-                key = ("enc", ph // s_, pw // s_, T)
+                Tprog = chunks[0][1]
+                key = ("enc", ph // s_, pw // s_, Tprog, T > 1)
                 prog = self._programs.get(key)
                 if prog is None:
-                    prog = _TileProgram(self, ph // s_, pw // s_, T, T, encoder=True)
+                    prog = _TileProgram(self, ph // s_, pw // s_, Tprog, Tprog, encoder=True)
                     if T > 1:
                         prog.cw = self.convs_clip
                     self._programs[key] = prog
                 prog.reset()
                 t = torch.empty(Tl, ph // s_, pw // s_, 64, dtype=torch.bfloat16, device=self.dev)
-                got = prog.run_encoder(img, i, j, t)
+                got = 0
+                for ci, (t0, nt) in enumerate(chunks):
+                    got += prog.run_encoder(img, i, j, t, t0=t0, nt=nt, chunked=chunked, first=(ci == 0), out_frame0=got)
                 assert got == Tl, (got, Tl)
                 row.append(t)
             rows.append(row)

@@ -106,3 +106,29 @@ def test_clip_encode_vs_oracle(T):
     one = vae.encode(x[:, :, :1].cuda(), tile_sample_min_size=32).latent_dist.parameters
     ref1 = vae_encode_moments(sd, ocfg, x[:, :, :1], use_tiling=True, tile_sample_min_size=32)
     assert rel_l2(one.float().cpu(), ref1) < 3e-2
+
+
+@pytest.mark.parametrize("T,win", [(33, 8), (33, 16), (41, 16), (9, 8)])
+def test_chunk_encode(T, win):
+    """sliding-window chunk_encode (modeling_causal_vae.py:310-341): window + 1 frames, then `window` per call (a short
+    remainder last), caches carried in the conv buffers' slots.  Same arithmetic per output element as the single pass,
+    so the two HIP results agree to rounding; both are checked against the oracle (which is pinned to the reference's
+    chunk_encode in tests/test_oracle_vs_reference.py)."""
+    from pyflow_hip.vae import CausalVideoVAE
+    from oracle.vae_oracle import vae_encode_moments
+    g = torch.load(GOLD)
+    sd = _vae_sd(g)
+    vae = CausalVideoVAE(sd, _vae_cfg(g), "cuda")
+    x = torch.randn(1, 3, T, 32, 48, generator=torch.Generator().manual_seed(9)).clamp(-1, 1)
+    ocfg = {k: g["vae_enc_cfg"][k] for k in ("encoder_block_out_channels", "encoder_layers_per_block",
+                                              "encoder_spatial_down_sample", "encoder_temporal_down_sample")}
+    ref = vae_encode_moments(sd, ocfg, x)
+    one = vae.encode(x.cuda()).latent_dist.parameters
+    chk = vae.encode(x.cuda(), temporal_chunk=True, window_size=win).latent_dist.parameters
+    assert chk.shape == ref.shape == (1, 32, 1 + (T - 1) // 8, 4, 6)
+    assert rel_l2(chk.float().cpu(), ref) < 3e-2
+    assert rel_l2(chk.float().cpu(), one.float().cpu()) < 2e-3        # GroupNorm sums are atomics: order may differ
+    vae.enable_tiling()
+    ref_t = vae_encode_moments(sd, ocfg, x, use_tiling=True, tile_sample_min_size=32)
+    chk_t = vae.encode(x.cuda(), temporal_chunk=True, window_size=win, tile_sample_min_size=32).latent_dist.parameters
+    assert rel_l2(chk_t.float().cpu(), ref_t) < 3e-2

@@ -166,6 +166,26 @@ def test_vae_encode_oracle(ref):
         assert (post.parameters - o).abs().max() < 2e-5
 
 
+def test_vae_chunk_encode_equals_single_pass(ref):
+    """chunk_encode (causal_vae.py:310-341, the sliding window with cache_front_feat) of the reference equals the
+    oracle's single causal pass: the restatement the HIP chunked encode is checked against; plain and tiled."""
+    from oracle import ref_harness as rh
+    from oracle.vae_oracle import vae_encode_moments
+    v = rh.build_ref_vae().eval()
+    cfg = dict(v.config)
+    x = torch.randn(1, 3, 33, 32, 48, generator=torch.Generator().manual_seed(6)).clamp(-1, 1)
+    with torch.no_grad():
+        for win in (8, 16):                  # 33 frames: 9 + 3 x 8 / 17 + 16
+            post = v.encode(x, temporal_chunk=True, window_size=win).latent_dist
+            o = vae_encode_moments(v.state_dict(), cfg, x)
+            assert post.parameters.shape == o.shape == (1, 32, 5, 4, 6)
+            assert (post.parameters - o).abs().max() < 5e-5
+        v.enable_tiling()
+        post = v.encode(x, temporal_chunk=True, window_size=8, tile_sample_min_size=32).latent_dist
+        o = vae_encode_moments(v.state_dict(), cfg, x, use_tiling=True, tile_sample_min_size=32)
+        assert (post.parameters - o).abs().max() < 5e-5
+
+
 def test_vae_encoder_key_table(ref):
     from pyflow_hip import synth
     v = ref.CausalVideoVAE(encoder_out_channels=16, decoder_in_channels=16,
