@@ -201,6 +201,7 @@ def test_pipeline_with_on_device_text_encoder():
     kw = dict(height=64, width=64, temp=2, num_inference_steps=[2, 2, 2], video_num_inference_steps=[1, 1, 1],
               guidance_scale=7.0, video_guidance_scale=5.0, output_type="latent")
     neg = "blurry, low quality"
+    torch.manual_seed(11)                      # the stage-transition block noise is drawn from the global RNG
     out = pipe.generate(prompt="a corgi surfing", negative_prompt=neg, generator=torch.Generator().manual_seed(5), **kw)
     assert torch.isfinite(out.float()).all()
 
@@ -210,6 +211,7 @@ def test_pipeline_with_on_device_text_encoder():
             return (t5(ti.input_ids, attention_mask=ti.attention_mask)[0].bfloat16(), ti.attention_mask,
                     cl(ci.input_ids).pooler_output.bfloat16())
     embeds = tuple(t.cuda() for t in hf("a corgi surfing, hyper quality, Ultra HD, 8K") + hf(neg))
+    torch.manual_seed(11)
     ref = pipe.generate(prompt_embeds=embeds, generator=torch.Generator().manual_seed(5), **kw)
     err = rel_l2(out.float().cpu(), ref.float().cpu())
     print("latents, on-device prompt encoders vs transformers embeddings:", err)
