@@ -38,6 +38,7 @@ struct Cfg {
     static constexpr int NT = BN / 64;                 // 32-column MFMA tiles per wave (wave tile 64 x BN/2)
     static constexpr int B_STAGE = BN * BK * 2;
     static constexpr int SMEM = A_BYTES + 2 * B_STAGE;
+    static constexpr int SMEM3 = A_BYTES + 3 * B_STAGE;   // variant 4: B triple-buffered as well (fits for BN = 128 only)
     static constexpr int EPI_STRIDE = BN / 2 + 4;      // floats per staged row
     static constexpr int EPI_BYTES = 32 * EPI_STRIDE * 4;
     static_assert(8 * EPI_BYTES <= SMEM, "epilogue strips must fit");
@@ -245,12 +246,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PF_BARRIER();          // every wave is done with the operand tiles before the epilogue strips overwrite them
     } else {
-    // ---- prologue: A(0), B(0), A(1)
+    // ---- prologue: A(0), B(0), A(1) (variant 4 also B(1): B runs two K-tiles ahead like A)
+    constexpr bool B3 = (V == 4);
     issueA(0, 0);
     issueB(0, 0);
     if (nk > 1) {
         issueA(1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (B3) {
+            issueB(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -259,11 +266,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
 
     int stage = 0;                     // A stage of tile kt = kt % 3
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = B3 ? stage : (kt & 1);
         const bool more2 = kt + 2 < nk;
-        // ---- slot L0: fragments of K-half 0, prefetch B(kt+1)
+        // ---- slot L0: fragments of K-half 0, prefetch B(kt+1) (variant 4: B(kt+2) into the stage tile kt-1 left)
         load_frags(stage, buf, 0);
-        if (kt + 1 < nk) issueB(kt + 1, buf ^ 1);
+        if (B3) {
+            if (more2) issueB(kt + 2, stage == 0 ? 2 : stage - 1);
+        } else if (kt + 1 < nk) {
+            issueB(kt + 1, buf ^ 1);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (V == 0) PF_BARRIER(); else PF_SCHED_FENCE();
         // ---- slot M0
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         if (more2) issueA(kt + 2, stage == 0 ? 2 : stage - 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (g == 1) {                  // group 1: this barrier is the one before group 0 reads tile kt+1
-            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B3 ? 4 + NT : 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PF_BARRIER();
         } else if (V == 0) {
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         // ---- slot M1
         mfma_slot();
         if (g == 0) {
-            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B3 ? 4 + NT : 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PF_BARRIER();
         } else if (V == 0 && kt + 1 < nk) {
@@ -386,13 +397,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
 template <int BN, bool CONV, int V>
 int launch(const Args& a, hipStream_t stream) {
     const int grid = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
+    constexpr int SM = (V == 4) ? Cfg<BN>::SMEM3 : Cfg<BN>::SMEM;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm256_kernel<BN, CONV, V>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            Cfg<BN>::SMEM);
+        hipFuncSetAttribute((const void*)gemm256_kernel<BN, CONV, V>, hipFuncAttributeMaxDynamicSharedMemorySize, SM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<BN, CONV, V>), dim3(grid), dim3(512), Cfg<BN>::SMEM, stream, a);
+    hipLaunchKernelGGL((gemm256_kernel<BN, CONV, V>), dim3(grid), dim3(512), SM, stream, a);
     return 0;
 }
 
@@ -417,10 +428,15 @@ int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
     return tiles >= 192 ? bn : 0;
 }
 
-int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream);
+int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream, int dbg = 0);
 
 int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
     if (variant == 3 && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream);
+    if ((variant == 5 || variant == 6) && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream, variant - 4);
+    // BN = 128 leaves room for a third B stage (144 KiB): B then runs two K-tiles ahead like A (+2-5 %); this is what the
+    // default variant 1 runs for BN = 128, variant 0 keeps the two-stage ping-pong form
+    if ((variant == 1 || variant == 4) && bn == 128)
+        return conv ? launch<128, true, 4>(a, stream) : launch<128, false, 4>(a, stream);
 #define PF_L(BN_) (conv ? (variant == 2 ? launch<BN_, true, 2>(a, stream) : launch<BN_, true, 1>(a, stream)) \
                         : (variant == 2 ? launch<BN_, false, 2>(a, stream) : (variant ? launch<BN_, false, 1>(a, stream) : launch<BN_, false, 0>(a, stream))))
     switch (bn) {
