@@ -191,6 +191,13 @@ int pf_blend_tiles(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb
 int pf_to_uint8(const void* tile, void* out, int T, int Ht, int Wt, int Cp, int crop_h, int crop_w, int H, int W,
                 int y0, int x0, pf_stream_t stream);
 
+/* video egress (the step after the path: diffusers.utils.export_to_video(frames, path, fps=24), inference_multigpu.py:92):
+ * uint8 RGB frames [T][H][W][3] -> planar Y [T][H][W] and Cb / Cr [T][H/2][W/2], JFIF full-range BT.601 in 16-bit fixed
+ * point (Y = (19595 R + 38470 G + 7471 B + 2^15) >> 16; chroma from the 2x2 block sums), the planes a YUV4MPEG2 stream or
+ * an encoder takes.  H and W even.  y_frame_stride / c_frame_stride: bytes between consecutive frames of the Y plane and
+ * of each chroma plane (0 = dense planes; H*W*3/2 for both packs whole I420 frames [Y | Cb | Cr] back to back). */
+int pf_rgb_to_yuv420(const void* rgb, void* y, void* u, void* v, int T, int H, int W, long long y_frame_stride,
+                     long long c_frame_stride, pf_stream_t stream);
 
 /* ------------------------------------------------------------------ prompt encoders --------------
  * The step before the sampling path: FluxTextEncoderWithMask (pyramid_dit/flux_modules/modeling_text_encoder.py:15-134)

@@ -67,7 +67,7 @@ EXPORTS = [
     "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
     "pf_copy_rows", "pf_sp_relayout", "pf_renoise_upsample", "pf_avgpool2",
     "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",
-    "pf_embed_rows", "pf_rmsnorm", "pf_glu_mul", "pf_attention_small_bf16",
+    "pf_embed_rows", "pf_rmsnorm", "pf_glu_mul", "pf_attention_small_bf16", "pf_rgb_to_yuv420",
 ]
 
 

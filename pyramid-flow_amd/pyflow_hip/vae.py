@@ -475,6 +475,12 @@ class CausalVideoVAE:
                 store[n] = (w.to(self.dev, torch.bfloat16).contiguous(), b.to(self.dev))
         self._programs = {}
         self.n_streams = 4          # concurrent tile decodes (HIP streams); 1 = strictly sequential
+        # Temporal chunks of chunk_decode are run `chunk_coalesce` windows at a time.  The chunk cache makes every
+        # chunking of the clip compute the same values (causal_conv.py:128-143; per-frame GroupNorm), so this changes only
+        # the launch shapes: with the reference's window_size = 1 the latent-resolution layers are 1 024-row GEMMs (32
+        # workgroups on 256 CUs); four windows at once quadruple their rows.  Activation memory grows by the same factor
+        # (a few GB per tile program at 768p); 1 = the reference's schedule literally.
+        self.chunk_coalesce = 4
         self._streams = []
 
     def enable_tiling(self, use_tiling=True):
@@ -550,7 +556,7 @@ class CausalVideoVAE:
         z = z[0].to(self.dev, torch.float32).contiguous()
         Cc, T, H, W = z.shape
         tl = int(tile_sample_min_size / self.downsample_scale)
-        sizes = tuple(self.chunk_sizes(T, window_size, temporal_chunk))
+        sizes = tuple(self.chunk_sizes(T, window_size * max(1, self.chunk_coalesce), temporal_chunk))
         if not (self.use_tiling and (W > tl or H > tl)):
             if comm is not None and comm.world > 1 and comm.rank != 0:
                 return None, None                  # nothing to split: rank 0 decodes alone (reference behaviour)

@@ -20,8 +20,9 @@ def _oracle_cfg(cfg):
                 decoder_spatial_up_sample=cfg["spatial_up_sample"], decoder_temporal_up_sample=cfg["temporal_up_sample"])
 
 
-@pytest.mark.parametrize("T,h,w,window", [(1, 6, 10, 1), (3, 6, 10, 1), (4, 8, 8, 2)])
-def test_decode_vs_oracle(T, h, w, window):
+@pytest.mark.parametrize("coalesce", [1, 4])
+@pytest.mark.parametrize("T,h,w,window", [(1, 6, 10, 1), (3, 6, 10, 1), (4, 8, 8, 2), (11, 6, 6, 1)])
+def test_decode_vs_oracle(T, h, w, window, coalesce):
     from pyflow_hip import synth
     from pyflow_hip.vae import CausalVideoVAE
     from oracle.vae_oracle import vae_decode
@@ -30,6 +31,7 @@ def test_decode_vs_oracle(T, h, w, window):
     z = torch.randn(1, 16, T, h, w, generator=torch.Generator().manual_seed(2))
     ref = vae_decode(sd, _oracle_cfg(cfg), z)
     vae = CausalVideoVAE(sd, cfg, "cuda")
+    vae.chunk_coalesce = coalesce        # 1 = the reference's chunk schedule literally, 4 = the default launch shapes
     out = vae.decode(z.cuda(), temporal_chunk=True, window_size=window).sample.float().cpu()
     assert out.shape == ref.shape
     assert rel_l2(out, ref) < 3e-2
