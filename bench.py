@@ -241,17 +241,26 @@ def main():
     dom = max(recs, key=lambda n: recs[n]["ms_timed"]) if recs else None
     roof = recs.pop(dom) if dom else None
     extra = recs
-    if roof is not None and roof["kernel"].startswith("gemm256_kernel"):
-        try:     # HBM traffic of that kernel: rocprofv3 --pmc passes committed under profiles/
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
-                pm = json.load(f)["kernels"]
-            k = next(v for n, v in pm.items() if roof["kernel"].split(">")[0] in n)
-            roof["traffic"] = round(k["hbm_bytes_per_launch"])
-            roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
-                                    "the launches of one full-width forward at L=15488 (profiles/r01_pmc_forward_maxL.json); "
-                                    "counted at the L2<->fabric interface incl. Infinity-Cache hits")
-        except Exception:
-            pass
+    # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (one full-width forward at L = 15 488)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
+            pm = json.load(f)["kernels"]
+    except Exception:
+        pm = {}
+
+    def pmc_traffic(name):
+        key = {"attention": "attn_kernel", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name.split(">")[0] + ",")
+        for n, v in pm.items():
+            if key in n:
+                return round(v["hbm_bytes_per_launch"])
+        return None
+    for r in [roof] + list(extra.values()):
+        if r is not None:
+            r["traffic"] = pmc_traffic(r["kernel"])
+    if roof is not None and roof["traffic"] is not None:
+        roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
+                                "the launches of one full-width forward at L=15488 (profiles/r01_pmc_forward_maxL.json); "
+                                "counted at the L2<->fabric interface incl. Infinity-Cache hits")
     value = frames_per_video * args.steps * (1 if use_sp else world) / dt
     res = {
         "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling",
