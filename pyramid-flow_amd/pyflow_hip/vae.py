@@ -27,11 +27,22 @@ def _ru(x, m):
 class PBuf:
     """padded channels-last activation with 2 temporal cache slots."""
 
-    def __init__(self, name, Tmax, H, W, Cc, device):
+    def __init__(self, name, Tmax, H, W, Cc, device, pool=None):
         self.name, self.T, self.H, self.W, self.C = name, Tmax, H, W, Cc
         self.Cp, self.Hp, self.Wp = _ru(Cc, 64), H + 2, W + 2
         self.fs = self.Hp * self.Wp * self.Cp
-        self.t = torch.zeros((Tmax + 2) * self.fs, dtype=torch.bfloat16, device=device)
+        n = (Tmax + 2) * self.fs
+        if pool is None:
+            self.t = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        else:
+            # storage shared by the tile programs of one decode lane (they run one at a time): the buffer of this name,
+            # grown to the largest geometry seen; the view is zeroed because the padding ring must read as zeros
+            st = pool.get(name)
+            if st is None or st.numel() < n:
+                st = torch.empty(n, dtype=torch.bfloat16, device=device)
+                pool[name] = st
+            self.t = st[:n]
+            self.t.zero_()
         self.cur = 0          # frames valid in slots [2, 2+cur)
         self.halo = None      # context-parallel mode: comm whose previous rank supplies the two cache slots
 
@@ -144,9 +155,10 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
 class _TileProgram:
     """all buffers + the layer sequence for one latent tile geometry (th x tw)."""
 
-    def __init__(self, vae, th, tw, t_first, t_later, encoder=False):
+    def __init__(self, vae, th, tw, t_first, t_later, encoder=False, pool=None):
         self.vae, self.th, self.tw = vae, th, tw
         self.bufs = {}
+        self.pool = pool            # dict name -> storage shared with the other programs of the same lane (or None)
         self.dev = vae.dev
         self.cw = vae.convs         # conv weight set (the clip encoder swaps in the full 3-tap encoder filters)
         cfg = vae.cfg
@@ -176,12 +188,19 @@ class _TileProgram:
     def buf(self, name, level_t, H, W, Cc):
         b = self.bufs.get(name)
         if b is None:
-            b = PBuf(name, self.tmax[level_t], H, W, Cc, self.dev)
+            b = PBuf(name, self.tmax[level_t], H, W, Cc, self.dev, self.pool)
             b.halo = getattr(self, "halo", None)
             self.bufs[name] = b
         return b
 
     def reset(self):
+        if self.pool is not None and self.pool.get("__owner__") is not self:
+            # another geometry used this lane's storage since: its data sits where this program's padding rings are
+            for b in self.bufs.values():
+                b.t.zero_()
+                b.cur = 0
+            self.pool["__owner__"] = self
+            return
         for b in self.bufs.values():
             b.reset()
 
@@ -474,6 +493,7 @@ class CausalVideoVAE:
                 b[:top] = sd[a + n + ".bias"]
                 store[n] = (w.to(self.dev, torch.bfloat16).contiguous(), b.to(self.dev))
         self._programs = {}
+        self._lane_pools = {}
         self.n_streams = 4          # concurrent tile decodes (HIP streams); 1 = strictly sequential
         # Temporal chunks of chunk_decode are run `chunk_coalesce` windows at a time.  The chunk cache makes every
         # chunking of the clip compute the same values (causal_conv.py:128-143; per-frame GroupNorm), so this changes only
@@ -508,7 +528,9 @@ class CausalVideoVAE:
         key = (th, tw, sizes[0], max(sizes[1:] or [sizes[0]]), lane)
         p = self._programs.get(key)
         if p is None:
-            p = _TileProgram(self, th, tw, key[2], key[3])
+            # the (up to 4) tile geometries of a frame size and every chunk schedule alias one storage pool per lane:
+            # activation memory = n_streams x the largest program instead of the sum over geometries
+            p = _TileProgram(self, th, tw, key[2], key[3], pool=self._lane_pools.setdefault(lane, {}))
             self._programs[key] = p
         return p
 

@@ -15,13 +15,19 @@ vae = CausalVideoVAE(sd, synth.VAE_DEFAULT, dev)
 vae.enable_tiling()
 T = int(os.environ.get("VAE_T", 31))
 z = torch.randn(1, 16, T, 96, 160, device=dev)
-for ns in [int(a) for a in sys.argv[1:]] or [1, 4]:
-    vae.n_streams = ns
+# args: "streams:coalesce" pairs, e.g. 4:1 4:4 4:8
+for arg in sys.argv[1:] or ["1:4", "4:4"]:
+    ns, co = (int(a) for a in (arg.split(":") + ["4"])[:2])
+    vae.n_streams, vae.chunk_coalesce = ns, co
+    vae._programs.clear()
+    vae._lane_pools.clear()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     vae.decode_to_uint8(z[:, :, :2], window_size=1, tile_sample_min_size=256)      # warm-up / allocations
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"n_streams={ns}: {dt:.2f} s for {out.shape[0]} frames ({7.51e15 * (out.shape[0] / 241) / dt / 1e12:.0f} TFLOP/s conv-equivalent) "
+    print(f"n_streams={ns} chunk_coalesce={co}: peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB  {dt:.2f} s for {out.shape[0]} frames ({7.51e15 * (out.shape[0] / 241) / dt / 1e12:.0f} TFLOP/s conv-equivalent) "
           f"checksum {int(out[::16, ::64, ::64].sum())}", flush=True)
