@@ -195,6 +195,8 @@ def main():
                              video_num_inference_steps=stepsv, guidance_scale=7.0, video_guidance_scale=5.0,
                              generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
 
+    if use_sp:
+        pipe.sp.warm_p2p(device)        # channel set-up of the tile-parallel decode's point-to-point pairs
     # lazy code-object loading / first allocations are initialisation, not a step
     pipe.generate(prompt_embeds=embeds, height=64, width=64, temp=2, num_inference_steps=[1, 1, 1],
                   video_num_inference_steps=[1, 1, 1], guidance_scale=7.0, video_guidance_scale=5.0,

@@ -180,6 +180,20 @@ class SPComm:
         if staged and hr is not None:
             recv_t.copy_(hr)
 
+    def warm_p2p(self, device):
+        """Create the point-to-point channels the tile-parallel decode uses (neighbour strips r -> r+1, column blocks
+        r -> 0) before anything is timed: RCCL sets a pair's channel up lazily at its first send / recv."""
+        if self.world == 1:
+            return
+        t = torch.zeros(8, dtype=torch.float32, device=device)
+        r = torch.empty_like(t)
+        self.shift(t, r)
+        if self.rank == 0:
+            for src in range(1, self.world):
+                self.recv(r, src)
+        else:
+            self.send(t, 0)
+
     def recv(self, t, src):
         if self.native or t.device.type == "cpu":
             dist.recv(t, self._global(src), group=self.group)
