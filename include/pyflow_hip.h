@@ -55,9 +55,10 @@ int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
  * 256, the 128 x 128 kernel otherwise), -1 = always the 128 x 128 kernel, 128/192/256 = force the 256 x BN kernel
  * whenever BN divides N.  Default 0, or the PF_GEMM256 environment variable. */
 int pf_gemm_set_policy(int force);
-/* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N): 0 = gemm_kernel (128x128), otherwise the BN of
- * gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */
-int pf_gemm_which(int M, int batch, int N);
+/* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), BN > 0 =
+ * gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN> (the 4-wave form, taken for K >= 7680) -- lets a profiler attribute
+ * launches to the kernel names rocprofv3 reports */
+int pf_gemm_which(int M, int batch, int N, int K);
 
 /* ------------------------------------------------------------------ CausalConv3d ----------------
  * Implicit-GEMM convolution over a channels-last, zero-padded input (replaces CausalConv3d.forward,

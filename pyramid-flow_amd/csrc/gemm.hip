@@ -223,8 +223,10 @@ extern "C" int pf_gemm_set_policy(int force) {
     g_gemm256_force = force;
     return 0;
 }
-extern "C" int pf_gemm_which(int M, int batch, int N) {   // tile width pf_gemm_bf16 would use: 0 = 128x128 kernel, else 256xBN
-    return pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
+extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, BN = gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN>
+    const int bn = pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
+    const bool w4 = (bn == 192 || bn == 256) && (g_gemm256_variant == 3 || (g_gemm256_variant == 1 && K >= 7680));
+    return w4 ? -bn : bn;
 }
 extern "C" int pf_gemm_set_variant(int v) {     // tuning hook, not part of the documented ABI
     g_gemm256_variant = v;

@@ -58,8 +58,8 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.strideA, d.strideC, d.strideR = strideA, strideC, strideR
     d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
     if PROFILER.enabled:      # attribute the launch to the kernel rocprofv3 will name
-        bn = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N))
-        name = f"gemm256_kernel<{bn}>" if bn else "gemm_kernel(128x128)"
+        bn = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K))
+        name = f"gemm256_kernel<{bn}>" if bn > 0 else (f"gemm256w4_kernel<{-bn}>" if bn < 0 else "gemm_kernel(128x128)")
     else:
         name = "gemm"
     PROFILER.launch(name, 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
