@@ -56,7 +56,7 @@ int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
  * whenever BN divides N.  Default 0, or the PF_GEMM256 environment variable. */
 int pf_gemm_set_policy(int force);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), BN > 0 =
- * gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN> (the 4-wave form, taken for K >= 7680) -- lets a profiler attribute
+ * gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN> (the 4-wave form, pf_gemm_set_variant(3)) -- lets a profiler attribute
  * launches to the kernel names rocprofv3 reports */
 int pf_gemm_which(int M, int batch, int N, int K);
 

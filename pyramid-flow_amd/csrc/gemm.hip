@@ -225,7 +225,8 @@ extern "C" int pf_gemm_set_policy(int force) {
 }
 extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, BN = gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN>
     const int bn = pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
-    const bool w4 = (bn == 192 || bn == 256) && (g_gemm256_variant == 3 || (g_gemm256_variant == 1 && K >= 7680));
+    (void)K;
+    const bool w4 = (bn == 192 || bn == 256) && g_gemm256_variant == 3;
     return w4 ? -bn : bn;
 }
 extern "C" int pf_gemm_set_variant(int v) {     // tuning hook, not part of the documented ABI

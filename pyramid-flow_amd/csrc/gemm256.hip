@@ -432,9 +432,6 @@ int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream, in
 
 int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
     if (variant == 3 && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream);
-    // long reductions (ff2, K = 7 680; the single blocks' proj_out, K = 9 600): the 4-wave kernel's leaner main loop wins
-    // by 2-3 % once the per-tile prologue / epilogue is amortised (profiles/r01_gemm_operand_path_diagnostics.log)
-    if (variant == 1 && !conv && (bn == 256 || bn == 192) && a.K >= 7680) return pf_gemm256w4_launch(a, bn, conv, stream);
     if ((variant == 5 || variant == 6) && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream, variant - 4);
     // BN = 128 leaves room for a third B stage (144 KiB): B then runs two K-tiles ahead like A (+2-5 %); this is what the
     // default variant 1 runs for BN = 128, variant 0 keeps the two-stage ping-pong form

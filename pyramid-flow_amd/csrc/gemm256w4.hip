@@ -9,7 +9,9 @@
 // double-buffered, counted vmcnt), one barrier per K-tile.
 //
 // Measured (profiles/r01_gemm_operand_path_diagnostics.log, M = 30 976): equal to the 8-wave kernel at K >= 7 680
-// (1.14-1.31 PFLOP/s), 3-4 % behind at K = 1 920 where the per-tile prologue / 4-wave epilogue weighs more.  The DBG
+// (1.14-1.31 PFLOP/s), 3-4 % behind at K = 1 920 where the per-tile prologue / 4-wave epilogue weighs more, and behind
+// on the smaller M of the early units: routing the K >= 7 680 GEMMs of a whole C3 video to it cost 2 % of their time
+// (profiles/r01_c3_rocprofv3_kernel_stats_v4_w4_longK.csv), so the default stays the 8-wave kernel.  The DBG
 // builds bound the loop from above: without the steady-state LDS-DMA loads it runs 1.52-1.61 PFLOP/s, without DMA
 // and fragment reads 1.65-1.75 -- the 25-33 % are the ISSUE cost of the LDS-DMA pieces (16 x 1 KiB per wave and
 // K-tile, tens of cycles each, MI355X_MICROARCH.md) which a lone wave per SIMD cannot hide behind MFMAs.  Moving the

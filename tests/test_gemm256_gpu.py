@@ -28,7 +28,7 @@ def policy(request):
     (128, 256, 128, 64), (128, 700, 384, 192), (192, 256, 192, 64), (192, 1000, 384, 1920), (192, 77, 576, 128),
     (256, 513, 512, 256), (256, 3000, 256, 640), (192, 2048 + 5, 1920, 320),
     (256, 700, 5760, 128), (256, 300, 328, 192), (256, 1024, 13440, 64),          # N tail of the 256-wide tile
-    (192, 600, 384, 7680), (256, 520, 512, 9600),       # long K: the default variant hands these to the 4-wave kernel
+    (192, 600, 384, 7680), (256, 520, 512, 9600),       # long reductions (ff2 / proj_out of the single blocks)
 ])
 def test_gemm256_bias(policy, bn, M, N, K):
     from pyflow_hip import ops
