@@ -175,8 +175,22 @@ def main():
         # PF_DIST_BACKEND=gloo: plumbing test of the N > 1 path on a box with fewer GPUs than ranks (tests only)
         dist.init_process_group(os.environ.get("PF_DIST_BACKEND", "nccl"))
         if use_sp:      # must exist before the model is built (reference contract, inference_multigpu.py:34-39)
-            from pyflow_hip.sp import init_sequence_parallel_group
-            init_sequence_parallel_group(sp_group_size=world)
+            from pyflow_hip import sp as sp_mod
+            comm = sp_mod.init_sequence_parallel_group(sp_group_size=world)
+            # every collective of the path once, with known values, before any model is built; if a rank cannot run it
+            # all ranks agree to fall back to independent replicas (reported as such in the JSON line)
+            ok = 1
+            try:
+                comm.selftest(device)
+            except Exception as e:          # noqa: BLE001
+                print(f"[bench] rank {rank}: sequence-parallel self-test failed ({e!r}); falling back to replicas",
+                      file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([1.0 - ok], dtype=torch.float32, device=device)
+            comm.all_reduce(flag)              # number of ranks that failed
+            if float(flag.item()) > 0:
+                use_sp = False
+                sp_mod._SP = None
 
     H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
     i2v = args.workload.startswith("c4")
@@ -195,8 +209,6 @@ def main():
                              video_num_inference_steps=stepsv, guidance_scale=7.0, video_guidance_scale=5.0,
                              generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
 
-    if use_sp:
-        pipe.sp.warm_p2p(device)        # channel set-up of the tile-parallel decode's point-to-point pairs
     # lazy code-object loading / first allocations are initialisation, not a step
     pipe.generate(prompt_embeds=embeds, height=64, width=64, temp=2, num_inference_steps=[1, 1, 1],
                   video_num_inference_steps=[1, 1, 1], guidance_scale=7.0, video_guidance_scale=5.0,

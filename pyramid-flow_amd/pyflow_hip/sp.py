@@ -194,6 +194,31 @@ class SPComm:
         else:
             self.send(t, 0)
 
+    def selftest(self, device):
+        """One round of every collective the sampling path uses, with known values: uneven all_to_all (rank r sends
+        p + 1 elements of value 100 r + p to rank p), all_reduce, broadcast, and the point-to-point channels.  Raises on a
+        wrong value; transport errors propagate."""
+        P, r = self.world, self.rank
+        send_spl = [p + 1 for p in range(P)]
+        recv_spl = [r + 1] * P
+        send = torch.cat([torch.full((p + 1,), float(100 * r + p)) for p in range(P)]).to(device=device, dtype=torch.bfloat16)
+        recv = torch.empty(sum(recv_spl), dtype=torch.bfloat16, device=device)
+        h = self.all_to_all(recv, send, recv_spl, send_spl, async_op=self.native)
+        if h is not None:
+            h.wait()
+        exp = torch.cat([torch.full((r + 1,), float(100 * p + r)) for p in range(P)]).to(torch.bfloat16)
+        if not torch.equal(recv.cpu(), exp):
+            raise RuntimeError("sequence-parallel self-test: all_to_all delivered wrong data")
+        t = torch.full((4,), float(r + 1), device=device)
+        self.all_reduce(t)
+        if not bool((t.cpu() == P * (P + 1) / 2).all()):
+            raise RuntimeError("sequence-parallel self-test: all_reduce delivered wrong data")
+        b = torch.full((3,), float(r), device=device)
+        self.broadcast(b, 0)
+        if not bool((b.cpu() == 0).all()):
+            raise RuntimeError("sequence-parallel self-test: broadcast delivered wrong data")
+        self.warm_p2p(device)
+
     def recv(self, t, src):
         if self.native or t.device.type == "cpu":
             dist.recv(t, self._global(src), group=self.group)

@@ -66,7 +66,7 @@ def _worker(rank, world, port, H, L, Lt, B, q):
     bc = torch.full((3,), float(rank))
     comm.broadcast(bc, 0)
     ok4 = bool((bc == 0).all())
-    comm.warm_p2p("cpu")           # neighbour + to-rank-0 channel set-up: must complete without deadlock on every rank
+    comm.selftest("cpu")           # what bench.py runs first at N > 1: every collective once with known values + p2p set-up
     q.put((rank, ok1, ok2, ok3, ok4))
     dist.barrier()
     dist.destroy_process_group()
