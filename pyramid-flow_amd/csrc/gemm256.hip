@@ -429,8 +429,10 @@ int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
 }
 
 int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream, int dbg = 0);
+int pf_gemm256p_launch(const Args& a, int bn, bool conv, hipStream_t stream);
 
 int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
+    if (variant == 10) return pf_gemm256p_launch(a, bn, conv, stream);            // persistent tile walk (gemm256p.hip)
     if (variant == 3 && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream);
     if ((variant == 5 || variant == 6) && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream, variant - 4);
     // BN = 128 leaves room for a third B stage (144 KiB): B then runs two K-tiles ahead like A (+2-5 %); this is what the

@@ -15,10 +15,10 @@ def _mk(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
-@pytest.fixture(params=[0, 1, 2, 3])
+@pytest.fixture(params=[0, 1, 2, 3, 10])
 def policy(request):
     from pyflow_hip import ops
-    ops.L.load().pf_gemm_set_variant(request.param)     # 0: barrier per slot, 1: one barrier per K-tile, 2: register-prefetch pipeline, 3: four waves with 128-row wave tiles
+    ops.L.load().pf_gemm_set_variant(request.param)     # 0: barrier per slot, 1: one barrier per K-tile, 2: register-prefetch pipeline, 3: four waves with 128-row wave tiles, 10: persistent tile walk
     yield ops.gemm_set_policy
     ops.gemm_set_policy(0)
     ops.L.load().pf_gemm_set_variant(1)
@@ -29,6 +29,7 @@ def policy(request):
     (256, 513, 512, 256), (256, 3000, 256, 640), (192, 2048 + 5, 1920, 320),
     (256, 700, 5760, 128), (256, 300, 328, 192), (256, 1024, 13440, 64),          # N tail of the 256-wide tile
     (192, 600, 384, 7680), (256, 520, 512, 9600),       # long reductions (ff2 / proj_out of the single blocks)
+    (192, 5120 + 7, 2688, 192), (256, 4100, 4352, 128), (128, 4100, 2304, 64),   # > 256 tiles: several tiles per persistent workgroup
 ])
 def test_gemm256_bias(policy, bn, M, N, K):
     from pyflow_hip import ops
