@@ -45,7 +45,7 @@ def bench_gemm():
         bias = torch.zeros(N, device="cuda")
         line = f"gemm M={Mx} N={N} K={K} gelu_from={gelu}:"
         lib = ops.L.load()
-        for pol, var in ((128, 1), (128, 10), (192, 1), (192, 10), (256, 1), (256, 10)):
+        for pol, var in ((-1, 0), (128, 1), (192, 1), (192, 3), (192, 10), (256, 1), (256, 3), (256, 10)):
             if pol > 0 and N % pol:
                 continue
             ops.gemm_set_policy(pol)
