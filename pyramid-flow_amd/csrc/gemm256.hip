@@ -245,6 +245,66 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PF_BARRIER();          // every wave is done with the operand tiles before the epilogue strips overwrite them
+    } else if constexpr (V == 11) {
+    // ---- variant 11 (diagnostic): variant 1's loop with s_memtime stamps around the four slots and the two barrier
+    // waits; workgroup 0 writes per-wave cycle sums to p.gate (float[8 waves][8]: L0, M0, L1, wait+barrier (group 1),
+    // M1, wait+barrier (group 0), K-tiles).  Stamps cost time themselves: read the numbers as proportions.
+    issueA(0, 0);
+    issueB(0, 0);
+    if (nk > 1) {
+        issueA(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PF_BARRIER();
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long {
+        PF_SCHED_FENCE();
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PF_SCHED_FENCE();
+        return t;
+    };
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more2 = kt + 2 < nk;
+        const unsigned long long t0 = now();
+        load_frags(stage, buf, 0);
+        if (kt + 1 < nk) issueB(kt + 1, buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = now();
+        mfma_slot();
+        const unsigned long long t2 = now();
+        load_frags(stage, buf, 1);
+        if (more2) issueA(kt + 2, stage == 0 ? 2 : stage - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t3 = now();
+        if (g == 1) {
+            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PF_BARRIER();
+        }
+        const unsigned long long t4 = now();
+        mfma_slot();
+        const unsigned long long t5 = now();
+        if (g == 0) {
+            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PF_BARRIER();
+        }
+        const unsigned long long t6 = now();
+        acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2;
+        acc_t[3] += t4 - t3; acc_t[4] += t5 - t4; acc_t[5] += t6 - t5;
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    if (blockIdx.x == 0 && lane == 0 && p.gate) {
+        float* o = const_cast<float*>(p.gate) + wid * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = (float)acc_t[k];
+        o[6] = (float)nk;
+    }
     } else {
     // ---- prologue: A(0), B(0), A(1) (variant 4 also B(1): B runs two K-tiles ahead like A)
     constexpr bool B3 = (V == 4);
@@ -432,6 +492,7 @@ int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream, in
 int pf_gemm256p_launch(const Args& a, int bn, bool conv, hipStream_t stream);
 
 int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
+    if (variant == 11 && !conv && bn != 128) return bn == 256 ? launch<256, false, 11>(a, stream) : launch<192, false, 11>(a, stream);
     if (variant == 10) return pf_gemm256p_launch(a, bn, conv, stream);            // persistent tile walk (gemm256p.hip)
     if (variant == 3 && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream);
     if ((variant == 5 || variant == 6) && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream, variant - 4);
