@@ -283,7 +283,7 @@ def main():
         "scaling": "strong" if use_sp else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: miniFLUX pyramid DiT (1.97 B params, 8+16 blocks, d=1920) + CausalVideoVAE "
-                               f"tiled(256)/chunked(1) decode, {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
+                               f"tiled(256)/chunked(1) decode (the reference's save_memory schedule; four chunk windows per launch set), {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
                                "CFG 7.0/5.0, random-init weights, synthetic prompt embeddings"
                                + (" [TINY MODEL: plumbing only]" if args.tiny_model else ""),
                    "parallelism": "single GPU" if world == 1 else (
