@@ -30,6 +30,7 @@ WORKLOADS = {
     "smoke_128p_17f": (128, 192, 3, [4, 4, 4], [2, 2, 2]),
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0          # HBM3E (same guide)
 
 
 def build_pipeline(device, tiny=False, mmdit=False):
@@ -255,6 +256,35 @@ def main():
     dom = max(recs, key=lambda n: recs[n]["ms_timed"]) if recs else None
     roof = recs.pop(dom) if dom else None
     extra = recs
+    # VAE decode kernels: one full 256 x 256 tile (5 latent frames -> 33 frames, the launch shapes of the timed decode) is
+    # decoded once more AFTER the timed region on a single stream with the per-launch profiler on: implicit-GEMM convs
+    # against the MFMA peak, GroupNorm + SiLU passes against the HBM peak (SURVEY 8d asks for both)
+    try:
+        if pipe.vae is not None:
+            ops.PROFILER.records = {}
+            keep_ns, pipe.vae.n_streams = pipe.vae.n_streams, 1
+            zt = torch.randn(1, 16, 5, 32, 32, device=device)
+            pipe.vae.decode_to_uint8(zt, window_size=1, tile_sample_min_size=256)       # allocations / first launches
+            ops.PROFILER.enabled = True
+            pipe.vae.decode_to_uint8(zt, window_size=1, tile_sample_min_size=256)
+            ops.PROFILER.enabled = False
+            pipe.vae.n_streams = keep_ns
+            torch.cuda.synchronize()
+            for name, sv in ops.PROFILER.summary().items():
+                if sv["ms_total"] <= 0 or name not in ("conv3d", "gn_stats", "gn_apply"):
+                    continue
+                rate = sv["work_total"] / (sv["ms_total"] * 1e-3)
+                hbm = name != "conv3d"
+                extra["vae:" + name] = dict(
+                    bound="hbm" if hbm else "mfma", achieved=round(rate / (1e9 if hbm else 1e12), 1),
+                    peak=PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS, unit="GB/s" if hbm else "TFLOP/s",
+                    frac=round(rate / ((PEAK_HBM_GBS * 1e9) if hbm else (PEAK_BF16_TFLOPS * 1e12)), 4), traffic=None,
+                    kernel=name, launches_timed=sv["launches"], avg_launch_ms=round(sv["ms_total"] / sv["launches"], 4),
+                    ms_timed=round(sv["ms_total"], 1), sampled="one 256x256-px tile, 33 frames, after the timed region")
+    except Exception as e:          # noqa: BLE001  (extra information only: never let it break the result line)
+        print(f"[bench] VAE kernel sample skipped: {e!r}", file=sys.stderr, flush=True)
+    finally:
+        ops.PROFILER.enabled = False
     # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (one full-width forward at L = 15 488)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
@@ -269,7 +299,7 @@ def main():
                 return round(v["hbm_bytes_per_launch"])
         return None
     for r in [roof] + list(extra.values()):
-        if r is not None:
+        if r is not None and r.get("traffic") is None:
             r["traffic"] = pmc_traffic(r["kernel"])
     if roof is not None and roof["traffic"] is not None:
         roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "

@@ -212,21 +212,24 @@ class _TileProgram:
         st = self.stats[:Tc * src.C * 2]
         st.zero_()
         lib = L.load()
-        check(lib.pf_gn_stats(C.c_void_p(src.t.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int(Tc), C.c_int(src.C),
-                              C.c_int(src.Cp), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Hp), C.c_int(src.Wp),
-                              C.c_longlong(src.fs), C.c_longlong(src.off(2)), stream()))
+        nbytes = 2.0 * Tc * src.H * src.W * src.C                       # one pass over the activation (bf16)
+        ops.PROFILER.launch("gn_stats", nbytes, lambda: check(lib.pf_gn_stats(
+            C.c_void_p(src.t.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int(Tc), C.c_int(src.C),
+            C.c_int(src.Cp), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Hp), C.c_int(src.Wp),
+            C.c_longlong(src.fs), C.c_longlong(src.off(2)), stream())))
         if dst_raw is None:
             args = (dst.t.data_ptr(), dst.Cp, dst.Hp, dst.Wp, dst.fs, dst.off(2))
             dst.cur = Tc
         else:
             t, cp = dst_raw
             args = (t.data_ptr(), cp, src.H, src.W, t.stride(0), 0)
-        check(lib.pf_gn_apply(C.c_void_p(src.t.data_ptr()), C.c_void_p(args[0]), C.c_void_p(st.data_ptr()),
-                              C.c_void_p(g.data_ptr()), C.c_void_p(bt.data_ptr()), C.c_int(Tc), C.c_int(src.C),
-                              C.c_int(v.groups), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Cp), C.c_int(src.Hp),
-                              C.c_int(src.Wp), C.c_longlong(src.fs), C.c_longlong(src.off(2)), C.c_int(args[1]),
-                              C.c_int(args[2]), C.c_int(args[3]), C.c_longlong(args[4]), C.c_longlong(args[5]),
-                              C.c_float(1e-6), C.c_int(int(silu)), stream()))
+        ops.PROFILER.launch("gn_apply", 2.0 * nbytes, lambda: check(lib.pf_gn_apply(
+            C.c_void_p(src.t.data_ptr()), C.c_void_p(args[0]), C.c_void_p(st.data_ptr()),
+            C.c_void_p(g.data_ptr()), C.c_void_p(bt.data_ptr()), C.c_int(Tc), C.c_int(src.C),
+            C.c_int(v.groups), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Cp), C.c_int(src.Hp),
+            C.c_int(src.Wp), C.c_longlong(src.fs), C.c_longlong(src.off(2)), C.c_int(args[1]),
+            C.c_int(args[2]), C.c_int(args[3]), C.c_longlong(args[4]), C.c_longlong(args[5]),
+            C.c_float(1e-6), C.c_int(int(silu)), stream())))
 
     def resnet(self, x, p, lvl, out_name, cout):
         """CausalResnetBlock3D.forward (modeling_resnet.py:115-150)."""
