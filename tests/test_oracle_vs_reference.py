@@ -235,3 +235,47 @@ def test_generate_i2v_oracle_vs_reference(ref):
                            forward_fn=mmdit_forward, image_latent=z)
     assert lat.shape == lat_ref.shape == (1, 16, 3, 8, 16)
     assert (lat - lat_ref).abs().max() < 1e-4
+
+
+def test_text_encoder_wrappers_vs_reference(ref):
+    """The composition the prompt-encoder GPU tests compare against (transformers' T5 encoder on the padded ids with the
+    tokenizer's mask; CLIP pooler_output / text_embeds; concatenation order) IS what the reference's wrapper classes
+    return: FluxTextEncoderWithMask / SD3TextEncoderWithMask instantiated without from_pretrained (tiny seeded
+    transformers models + the stub tokenizer), called through their own forward()."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "helpers"))
+    from hf_text import tiny_t5, tiny_clip, StubTokenizer
+    from pyramid_dit.flux_modules.modeling_text_encoder import FluxTextEncoderWithMask as RefFlux
+    from pyramid_dit.mmdit_modules.modeling_text_encoder import SD3TextEncoderWithMask as RefSD3
+    t5, t5cfg = tiny_t5(seed=1)
+    cl, clcfg = tiny_clip(seed=2)
+    clp, _ = tiny_clip(seed=2, projection=128)
+    cg, _ = tiny_clip(seed=3, act="gelu", projection=128)
+
+    class Tok(StubTokenizer):                       # the reference passes a few extra tokenizer kwargs
+        def __call__(self, prompts, **kw):
+            kw = {k: v for k, v in kw.items() if k in ("padding", "max_length", "truncation", "add_special_tokens", "return_tensors")}
+            return super().__call__(prompts, **kw)
+    tok_c, tok_t = Tok(clcfg.vocab_size, 77), Tok(t5cfg.vocab_size, 128)
+    prompts = ["a red panda eating bamboo, hyper quality"]
+    ti, ci = tok_t(prompts, max_length=128), tok_c(prompts, max_length=77)
+    with torch.no_grad():
+        exp_emb = t5(ti.input_ids, attention_mask=ti.attention_mask)[0]
+
+        rf = RefFlux.__new__(RefFlux)
+        torch.nn.Module.__init__(rf)
+        rf.tokenizer, rf.tokenizer_max_length, rf.text_encoder = tok_c, 77, cl
+        rf.tokenizer_2, rf.text_encoder_2 = tok_t, t5
+        emb, mask, pooled = rf(prompts, torch.device("cpu"))
+        assert torch.equal(emb, exp_emb) and torch.equal(mask, ti.attention_mask)
+        assert torch.equal(pooled, cl(ci.input_ids).pooler_output)
+
+        rs = RefSD3.__new__(RefSD3)
+        torch.nn.Module.__init__(rs)
+        rs.tokenizer, rs.tokenizer_max_length, rs.text_encoder = tok_c, 77, clp
+        rs.tokenizer_2, rs.text_encoder_2 = tok_c, cg
+        rs.tokenizer_3, rs.text_encoder_3 = tok_t, t5
+        emb3, mask3, pooled3 = rs(prompts, torch.device("cpu"))
+        assert torch.equal(emb3, exp_emb) and torch.equal(mask3, ti.attention_mask)
+        assert torch.equal(pooled3, torch.cat([clp(ci.input_ids).text_embeds, cg(ci.input_ids).text_embeds], -1))
