@@ -241,8 +241,13 @@ class PyramidDiTForVideoGeneration:
                 if self._round:
                     tv = float(torch.tensor(tv, dtype=torch.float64).to(torch.bfloat16))      # pipeline.py:750
                 vtok = self.dit.forward_tokens(plan, clips, [tv] * B, pooled, shared_clips=True)
-                ops.cfg_euler_step(vtok, vtok.stride(0), vtok.stride(1), x, C, h, w, gs, B == 2,
-                                   self.scheduler.dsigma(), self._round)
+                ds = self.scheduler.dsigma()
+                if self._round:
+                    # scheduling_flow_matching.py:283: `(sigma_next - sigma) * model_output` multiplies a 0-dim
+                    # float64 TENSOR with a bf16 tensor -- the 0-dim operand is converted to the common dtype (bf16)
+                    # before the product, so the reference's bf16 path steps with bf16(dsigma)
+                    ds = float(torch.tensor(ds, dtype=torch.float64).to(torch.bfloat16))
+                ops.cfg_euler_step(vtok, vtok.stride(0), vtok.stride(1), x, C, h, w, gs, B == 2, ds, self._round)
             outs.append(x)
         return outs
 

@@ -225,3 +225,54 @@ def test_small_elementwise():
     ops.avgpool2(noise, pooled, C_, H, W, 2.0)
     ref = F.interpolate(noise[None], size=(H // 2, W // 2), mode="bilinear")[0] * 2
     assert (pooled - ref).abs().max() < 1e-5
+
+
+def test_bf16_trajectory_rounding_points_bit_exact():
+    """round_bf16=True branches (what generate() runs with bf16 prompt embeddings, pipeline `_round`): the fused kernels
+    must reproduce the reference's op-by-op bf16 evaluation BIT FOR BIT -- CFG combine (pipeline.py:771-776), Euler step
+    (scheduling_flow_matching.py:278-286: bf16(dsigma*v) then fp32 add then bf16), renoise (:729-743) and the
+    bilinear /2 pyramids (:565, :1116).  The right-hand sides below are those expressions run by torch on CPU bf16
+    tensors."""
+    from pyflow_hip import ops
+    bf = torch.bfloat16
+    C_, H, W = 16, 8, 12
+    n = (H // 2) * (W // 2)
+    v = _mk((2, n, 128), 51).to(DEV)                                    # fp32 velocity tokens as the DiT leaves them
+    lat0 = bf16_round(_mk((C_, H, W), 52))
+    vv = v.cpu()[..., :64].reshape(2, H // 2, W // 2, 2, 2, C_).permute(0, 5, 1, 3, 2, 4).reshape(2, C_, H, W)
+    for gs, dsig in ((5.0, -0.0526315789), (7.0, -0.111), (1.0, -0.001)):
+        lat = lat0.clone().to(DEV)
+        # the pipeline hands the kernel bf16(dsigma): a 0-dim f64 tensor operand is converted to bf16 before the product
+        ds_k = float(torch.tensor(dsig, dtype=torch.float64).to(bf))
+        ops.cfg_euler_step(v, n * 128, 128, lat, C_, H, W, gs, True, ds_k, True)
+        npred = vv.to(bf)                                                # model output dtype
+        vu, vt = npred[0], npred[1]
+        comb = vu + gs * (vt - vu)                                       # bf16 op by op
+        assert comb.dtype == bf
+        step = torch.tensor(dsig, dtype=torch.float64) * comb            # 0-dim f64 x bf16 -> bf16 (Appendix B)
+        assert step.dtype == bf
+        ref = (lat0.float() + step).to(bf).float()
+        assert torch.equal(lat.cpu(), ref), (gs, dsig)
+    # no CFG: the model output is still bf16
+    lat = lat0.clone().to(DEV)
+    ops.cfg_euler_step(v, n * 128, 128, lat, C_, H, W, 0.0, False, float(torch.tensor(-0.05).to(bf)), True)
+    ref = (lat0.float() + torch.tensor(-0.05, dtype=torch.float64) * vv[0].to(bf)).to(bf).float()
+    assert torch.equal(lat.cpu(), ref)
+    # renoise: alpha * nearest_up(latents) + beta * noise.to(bf16), all bf16
+    xin = bf16_round(_mk((C_, H // 2, W // 2), 53))
+    noise = _mk((C_, H, W), 54)
+    xo = torch.zeros(C_, H, W, device=DEV)
+    alpha, beta = 0.5998800255395356, 0.693028124888686              # stage-1 coefficients (SURVEY Appendix B)
+    ops.renoise_upsample(xin.to(DEV), noise.to(DEV), xo, C_, H, W, alpha, beta, True)
+    up = F.interpolate(xin.to(bf)[None], size=(H, W), mode="nearest")[0]
+    ref = (alpha * up + beta * noise.to(bf)).float()
+    assert torch.equal(xo.cpu(), ref)
+    # pyramids: F.interpolate(bilinear, 1/2) [* 2] on bf16 tensors
+    src = bf16_round(_mk((C_, H, W), 55))
+    for mul in (1.0, 2.0):
+        pooled = torch.zeros(C_, H // 2, W // 2, device=DEV)
+        ops.avgpool2(src.to(DEV), pooled, C_, H, W, mul, True)
+        ref = F.interpolate(src.to(bf)[None], size=(H // 2, W // 2), mode="bilinear")[0]
+        if mul != 1.0:
+            ref = ref * mul
+        assert torch.equal(pooled.cpu(), ref.float()), mul
