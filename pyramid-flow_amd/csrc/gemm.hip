@@ -206,6 +206,8 @@ int pf_set_err(const char* m);
 #define set_err pf_set_err
 int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force);
 int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, int variant, hipStream_t stream);
+int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream);      // gemm8p.hip: persistent 256 x 256 tiles
+bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 
 // PF_GEMM256 = 0 (auto, default) | 128 | 192 | 256 (force that tile width when it divides N) | -1 (never)
 static int g_gemm256_force = -2;
@@ -217,15 +219,29 @@ static int gemm256_force() {
     }
     return g_gemm256_force;
 }
+// gemm8p (persistent 256 x 256 tiles): 1 = whenever legal (policy 8), 0 = automatic, -1 = never (policy -8)
+static int g_gemm8p_mode = 0;
+static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
+static bool use_gemm8p(int M, int batch, int N, int K) {
+    if (g_gemm8p_mode < 0 || N % 8 || K % 64) return false;
+    if (g_gemm8p_mode > 0) return true;
+    if (!g_gemm8p_auto || gemm256_force() != 0) return false;          // an explicit tile-width policy addresses the older kernels
+    // automatic: problems of at least one full round of 256 x 256 tiles whose N tail wastes < 7 % of the columns
+    const long long tiles = (long long)((M + 255) / 256) * batch * ((N + 255) / 256);
+    const int n256 = (N + 255) / 256 * 256;
+    return tiles >= 192 && (n256 - N) * 100 < 7 * N;
+}
 extern "C" int pf_gemm_set_policy(int force) {
+    if (force == 8 || force == -8) { g_gemm8p_mode = force > 0 ? 1 : -1; g_gemm256_force = 0; return 0; }
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
+    g_gemm8p_mode = 0;
     return 0;
 }
-extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, BN = gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN>
+extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN>
+    if (use_gemm8p(M, batch, N, K)) return 8;
     const int bn = pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
-    (void)K;
     const bool w4 = (bn == 192 || bn == 256) && g_gemm256_variant == 3;
     return w4 ? -bn : bn;
 }
@@ -238,7 +254,8 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
     if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
     const int bn256 = pf_gemm256_pick((long long)d->M * d->batch, d->M, d->batch, d->N, gemm256_force());
-    if (!bn256 && d->N % BN != 0) return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
+    if (!bn256 && d->N % BN != 0 && !use_gemm8p(d->M, d->batch, d->N, d->K))
+        return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (d->K % BK != 0 || d->K <= 0) return set_err("pf_gemm_bf16: K must be a positive multiple of 64");
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8)) return set_err("pf_gemm_bf16: leading dims must be multiples of 8");
     if ((d->flags & PF_GEMM_GATE_RES) && !d->res) return set_err("pf_gemm_bf16: GATE_RES needs res");
@@ -254,6 +271,12 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
         static int gmv = -1;
         if (gmv < 0) { const char* e = getenv("PF_GEMM_GROUPM"); gmv = e ? atoi(e) : 0; }
         a.group_m = gmv;
+    }
+    if (use_gemm8p(d->M, d->batch, d->N, d->K) && pf_gemm8p_supports(a, false)) {
+        pf_gemm8p_launch(a, false, stream);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
+        return 0;
     }
     if (const int bn = bn256) {
         pf_gemm256_launch(a, bn, false, g_gemm256_variant, stream);
@@ -287,6 +310,12 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
                     d->in_sh > 0 ? d->in_sh : 1, d->in_sw > 0 ? d->in_sw : 1, d->in_st > 0 ? d->in_st : 1};
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
+    if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) {
+        pf_gemm8p_launch(a, true, stream);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
+        return 0;
+    }
     if (const int bn = pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force())) {
         pf_gemm256_launch(a, bn, true, g_gemm256_variant, stream);
         hipError_t e2 = hipGetLastError();

@@ -48,8 +48,14 @@ def get_context_parallel_rank():
     return _CP.rank if _CP else 0
 
 
+def reset_context_parallel():
+    """test hook: forget the group"""
+    global _CP
+    _CP = None
+
+
 def conv_scatter_to_context_parallel_region(input_, dim=2, kernel_size=1):
-    """context_parallel_ops.py:14-38"""
+    """context_parallel_ops.py:14-38, 158-159"""
     P, r = get_context_parallel_world_size(), get_context_parallel_rank()
     if P == 1:
         return input_

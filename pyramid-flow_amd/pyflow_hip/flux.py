@@ -15,6 +15,7 @@ import torch
 from . import ops
 from .ops import GEMM_GATE_RES, GEMM_OUT_F32
 from .plan import SequencePlan
+from .refapi import DeviceModuleAPI, load_diffusers_dir
 
 
 def _bf16(t, device):
@@ -50,9 +51,11 @@ def _pad_n(w, b, mult=128):
 class FluxWeights:
     """Packs a reference-keyed state dict (SURVEY 8b key layout) into fused bf16 matrices."""
 
-    def __init__(self, sd, cfg, device, head_major=False):
+    def __init__(self, sd, cfg, device, head_major=False, blocks_only=False):
         """head_major: order the fused K|V|Q output columns per head ([h][k|v|q][64]) instead of per type -- the
-        layout of the sequence-parallel exchange buffers (a rank's heads are then one contiguous column block)."""
+        layout of the sequence-parallel exchange buffers (a rank's heads are then one contiguous column block).
+        blocks_only: `sd` holds transformer blocks only (the block-level operators of pyflow_hip/blocks.py): no
+        embedders, conditioning MLPs or output head are packed."""
         sd = {k: v.detach().float().cpu() for k, v in sd.items()}
         self.cfg = cfg
         self.head_major = head_major
@@ -64,12 +67,15 @@ class FluxWeights:
         # variant: miniFLUX ("pyramid_flux": x_embedder Linear, 3-axis RoPE, double + single blocks) or the SD3-style
         # MMDiT ("pyramid_mmdit", mmdit_modules/modeling_pyramid_mmdit.py:60-149: PatchEmbed3D conv + sincos table,
         # temporal RoPE over the whole head, joint blocks only, last block context_pre_only, QK-norm eps 1e-5)
-        self.mmdit = "pos_embed.proj.weight" in sd
+        self.mmdit = "pos_embed.proj.weight" in sd or bool(cfg.get("_mmdit_blocks"))
         nd, ns = cfg["num_layers"], (0 if self.mmdit else cfg["num_single_layers"])
         self.qk_eps = 1e-5 if self.mmdit else 1e-6
         self.rope_axes = [hd] if self.mmdit else list(cfg["axes_dims_rope"])
         dev = device
-        if self.mmdit:
+        if self.mmdit and blocks_only:
+            self.pos_table = None
+            added_q, added_k = "norm_add_q", "norm_add_k"
+        elif self.mmdit:
             # Conv2d(k=2, s=2) on a frame == Linear over the (c, p1, p2) patch; tokens arrive as (p1, p2, c)
             wc = sd["pos_embed.proj.weight"]
             sd["x_embedder.weight"] = wc.permute(0, 2, 3, 1).reshape(wc.shape[0], -1).contiguous()
@@ -105,6 +111,11 @@ class FluxWeights:
                 b_ = torch.cat([b_, Bv(extra)])
             return _bf16(w_, dev), _f32(b_, dev)
 
+        if not blocks_only:
+            self._pack_embedders(W, Bv, dev)
+        self._pack_blocks(sd, W, Bv, kvq, nd, ns, d, dev, added_q, added_k, blocks_only)
+
+    def _pack_embedders(self, W, Bv, dev):
         # conditioning MLPs (gemv, bf16 weights / fp32 bias)
         self.t1 = (_bf16(W("time_text_embed.timestep_embedder.linear_1"), dev), _f32(Bv("time_text_embed.timestep_embedder.linear_1"), dev))
         self.t2 = (_bf16(W("time_text_embed.timestep_embedder.linear_2"), dev), _f32(Bv("time_text_embed.timestep_embedder.linear_2"), dev))
@@ -119,6 +130,8 @@ class FluxWeights:
         self.x_b = _f32(Bv("x_embedder"), dev)
         self.in_ch = W("x_embedder").shape[1]
         assert self.x_w.shape[1] == self.in_ch, "in_channels must be a multiple of 64"
+
+    def _pack_blocks(self, sd, W, Bv, kvq, nd, ns, d, dev, added_q, added_k, blocks_only):
         # all AdaLN linears as one matrix (one gemv per forward)
         mods, mod_b = [], []
         self.dbl, self.sgl = [], []
@@ -155,26 +168,33 @@ class FluxWeights:
             blk["norm_q"] = _f32(sd[p + "attn.norm_q.weight"], dev)
             blk["norm_k"] = _f32(sd[p + "attn.norm_k.weight"], dev)
             self.sgl.append(blk)
-        mods.append(W("norm_out.linear"))
-        mod_b.append(Bv("norm_out.linear"))
-        self.mod_final = off
-        off += 2 * d
+        if not blocks_only:
+            mods.append(W("norm_out.linear"))
+            mod_b.append(Bv("norm_out.linear"))
+            self.mod_final = off
+            off += 2 * d
+            pw, pb = _pad_n(W("proj_out"), Bv("proj_out"))
+            self.proj_w, self.proj_b = _bf16(pw, dev), _f32(pb, dev)
+            self.out_cols = W("proj_out").shape[0]
         self.n_mod = off
         self.mod_w = _bf16(torch.cat(mods), dev)
         self.mod_b = _f32(torch.cat(mod_b), dev)
-        pw, pb = _pad_n(W("proj_out"), Bv("proj_out"))
-        self.proj_w, self.proj_b = _bf16(pw, dev), _f32(pb, dev)
-        self.out_cols = W("proj_out").shape[0]
         self.n_params = sum(v.numel() for v in sd.values())
 
 
-class FluxEngine:
+class FluxEngine(DeviceModuleAPI):
+    """`PyramidFluxTransformer` / `PyramidDiffusionMMDiT` of the reference (modeling_pyramid_flux.py:60-542,
+    modeling_pyramid_mmdit.py:60-497), inference half: same constructor source (`from_pretrained` on a diffusers
+    directory), same `forward(sample, encoder_hidden_states, encoder_attention_mask, pooled_projections,
+    timestep_ratio)` call and `.config`; the variant is read off the state dict."""
     HEAD_MAJOR = False
 
     def __init__(self, state_dict, cfg, device="cuda"):
+        import types
         self.dev = torch.device(device)
         self.w = FluxWeights(state_dict, cfg, self.dev, head_major=self.HEAD_MAJOR)
         self.cfg = cfg
+        self.config = types.SimpleNamespace(**dict(cfg))          # `.config.in_channels` (pipeline.py:1098)
         self._ws = {}
         self._ctx = None
         self._mod_cache = None
@@ -242,8 +262,14 @@ class FluxEngine:
         d = w.d
         # the modulation vectors are a function of (timestep, pooled prompt) only: every later unit repeats the
         # (stage, step) timesteps of unit 1, so 870 of the 960 forwards of a video hit this cache (1.07 GB of AdaLN
-        # weights not re-read per forward).  Keyed on the timestep values and the pooled tensor's identity.
-        key = (tuple(float(t) for t in timesteps), pooled.data_ptr(), pooled._version)
+        # weights not re-read per forward).  Keyed on the timestep values and the CONTENT of the pooled tensor: the
+        # bytes are fetched once per distinct tensor object / version (the tensor is kept referenced meanwhile, so its
+        # address cannot be recycled for another prompt), not per forward.
+        last = getattr(self, "_pooled_seen", None)
+        if last is None or last[0] is not pooled or last[1] != pooled._version:
+            last = (pooled, pooled._version, pooled.detach().to("cpu", torch.float32).numpy().tobytes())
+            self._pooled_seen = last
+        key = (tuple(float(t) for t in timesteps), last[2])
         cache = getattr(self, "_mod_cache", None)
         if cache is not None and key in cache:
             return cache[key], None
@@ -260,7 +286,9 @@ class FluxEngine:
         ops.gemv(w.p2[0], w.p2[1], h1, temb, d, d, B, silu_in=True, accumulate=True)
         mod = self._buf("mod", B * w.n_mod, torch.float32)
         ops.gemv(w.mod_w, w.mod_b, temb, mod, w.n_mod, d, B, silu_in=True)
-        if cache is not None and len(cache) < 256:
+        if cache is not None:
+            if len(cache) >= 128:             # one video uses <= 90 distinct (stage, step) timesteps: bound the cache
+                cache.pop(next(iter(cache)))
             mod = mod[:B * w.n_mod].clone()
             cache[key] = mod
         return mod, temb
@@ -268,22 +296,27 @@ class FluxEngine:
     def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):
         """clips: list of device tensors [B,C,t,h,w] (or [1,C,t,h,w] with shared_clips=True: the CFG
         duplicate of pipeline.py:747).  Returns v tokens fp32 [B, n_cur, 128] (first 4C columns valid)."""
+        ctx = ctx if ctx is not None else self._ctx
+        mod, _ = self.conditioning(timesteps, pooled)
+        self._embed_tokens(plan, clips, ctx, shared_clips, debug)
+        self._run_blocks(plan, mod, debug=debug)
+        return self._head(plan, mod)
+
+    def _geometry(self, plan):
         w = self.w
         d, H = w.d, w.H
         B, Lt, L, L_img, Lp = plan.B, plan.Lt, plan.L, plan.L_img, plan.Lp
-        ctx = ctx if ctx is not None else self._ctx
-        mod, _ = self.conditioning(timesteps, pooled)
-        nm = w.n_mod
         hidden = self._buf("hidden", B * L * d, torch.bfloat16)
         xn = self._buf("xn", B * L * d, torch.bfloat16)
         big = self._buf("big", B * L * 7 * d, torch.bfloat16)
         vT = self._buf("vT", B * H * 64 * Lp, torch.bfloat16)
-        tok = self._buf("tok", B * L_img * w.in_ch, torch.bfloat16)
-        Ld, L3, L4, L7 = L * d, L * 3 * d, L * 4 * d, L * 7 * d
-        mlp_base = B * L3          # mlp region of `big` for the double blocks
-        scale = 64 ** -0.5
-        qs = scale * ops.LOG2E     # folded into q by qk_norm_rope; attention then works in base-2 exponents
+        return w, d, H, B, Lt, L, L_img, Lp, hidden, xn, big, vT
 
+    def _embed_tokens(self, plan, clips, ctx, shared_clips=False, debug=None):
+        """text rows <- cached context, image rows <- x_embedder(patchify) (flux:284-290, 401)"""
+        w, d, H, B, Lt, L, L_img, Lp, hidden, xn, big, vT = self._geometry(plan)
+        tok = self._buf("tok", B * L_img * w.in_ch, torch.bfloat16)
+        Ld = L * d
         # ---- embed: text rows <- cached context, image rows <- x_embedder(patchify) ----
         ops.copy_rows(ctx, hidden, Lt, d, d, d, Lt * d, Ld, B)
         row = 0
@@ -305,6 +338,21 @@ class FluxEngine:
         if debug is not None:
             debug["hidden0"] = hidden[:B * L * d].view(B, L, d).clone()
 
+
+    def _run_blocks(self, plan, mod, dbl=None, sgl=None, last_block_tail=True, debug=None):
+        """the double-stream and single-stream blocks over the resident `hidden` buffer (flux:447-520).  `dbl` / `sgl`:
+        the packed blocks to run (default: all); last_block_tail=False computes every row of the last block too (the
+        block-level operators return all rows)."""
+        w, d, H, B, Lt, L, L_img, Lp, hidden, xn, big, vT = self._geometry(plan)
+        dbl = w.dbl if dbl is None else dbl
+        sgl = w.sgl if sgl is None else sgl
+        skip_dead = self.skip_dead_rows and last_block_tail
+        nm = w.n_mod
+        Ld, L3, L4, L7 = L * d, L * 3 * d, L * 4 * d, L * 7 * d
+        mlp_base = B * L3          # mlp region of `big` for the double blocks
+        scale = 64 ** -0.5
+        qs = scale * ops.LOG2E     # folded into q by qk_norm_rope; attention then works in base-2 exponents
+
         def ln(rows, x_off, sh, sc):
             ops.ln_modulate(hidden, xn, (mod, sh), (mod, sc), d, B, rows, Ld, Ld, d, d, nm, x_off=x_off, y_off=x_off)
 
@@ -312,7 +360,7 @@ class FluxEngine:
         # of the image stream between the two joins around the attention: it runs on a side HIP stream and fills CUs
         # the image GEMMs' tails leave idle.  Rows / buffer regions of the two streams are disjoint.
         main = torch.cuda.current_stream()
-        side = self._side_stream() if (self.overlap_text and w.dbl) else None
+        side = self._side_stream() if (self.overlap_text and dbl) else None
         if side is not None:
             side.wait_stream(main)
 
@@ -320,12 +368,12 @@ class FluxEngine:
             return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
 
         n_cur = plan.n_cur
-        for blk in w.dbl:
+        for blk in dbl:
             mb = blk["mod"]
             pre_only = blk["pre_only"]
             # last MMDiT block (context_pre_only, no single blocks follow): only the current frame's rows reach the
             # output -> K, V for every row, but Q / attention rows / to_out / MLP only for the last n_cur image rows
-            tail = pre_only and self.skip_dead_rows and not w.sgl and n_cur < L_img
+            tail = pre_only and skip_dead and not sgl and n_cur < L_img
             r0 = L - n_cur if tail else Lt                      # first image row that is computed in full
             n_act = L - r0
             with on_side():
@@ -381,10 +429,10 @@ class FluxEngine:
             main.wait_stream(side)
 
         n_cur = plan.n_cur
-        for bi, blk in enumerate(w.sgl):
+        for bi, blk in enumerate(sgl):
             mb = blk["mod"]
             ln(L, 0, mb, mb + d)
-            if self.skip_dead_rows and bi == len(w.sgl) - 1 and n_cur < L:
+            if skip_dead and bi == len(sgl) - 1 and n_cur < L:
                 # LAST block: only the current frame's rows reach the output (split_output keeps [-n_cur:],
                 # modeling_pyramid_flux.py:380).  K and V are still needed for every row, but Q, the MLP branch,
                 # the attention rows and proj_out only for the last n_cur rows -- identical values, less work.
@@ -413,7 +461,13 @@ class FluxEngine:
         if debug is not None:
             debug["hidden_final"] = hidden[:B * L * d].view(B, L, d).clone()
 
-        # ---- norm_out + proj_out on the current frame's tokens only (split_output keeps [-n_cur:], flux:380) ----
+
+    def _head(self, plan, mod):
+        """norm_out + proj_out on the current frame's tokens only (split_output keeps [-n_cur:], flux:380)"""
+        w, d, H, B, Lt, L, L_img, Lp, hidden, xn, big, vT = self._geometry(plan)
+        nm = w.n_mod
+        Ld = L * d
+        n_cur = plan.n_cur
         fo = (L - n_cur) * d
         mf = w.mod_final
         ops.ln_modulate(hidden, xn, (mod, mf + d), (mod, mf), d, B, n_cur, Ld, Ld, d, d, nm, x_off=fo, y_off=fo)
@@ -423,8 +477,38 @@ class FluxEngine:
                  strideC=n_cur * npad, flags=GEMM_OUT_F32, a_off=fo)
         return vtok[:B * n_cur * npad].view(B, n_cur, npad)
 
-    def forward(self, clips, enc, enc_mask, pooled, timesteps):
-        """Reference-shaped call: returns [B, C, t, h, w] fp32 of the LAST clip (flux:392-542)."""
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, torch_dtype=None, device="cuda", **config_overrides):
+        """pipeline.py:73-87: `PyramidFluxTransformer.from_pretrained(os.path.join(model_path, variant), torch_dtype=,
+        use_gradient_checkpointing=, use_flash_attn=, use_temporal_causal=, interp_condition_pos=, axes_dims_rope=, ...)`
+        -- keyword arguments override entries of config.json, exactly like diffusers' ModelMixin."""
+        sd, cfg = load_diffusers_dir(pretrained_model_path)
+        cfg.update({k: v for k, v in config_overrides.items() if v is not None})
+        if cfg.get("use_flash_attn"):
+            raise NotImplementedError("use_flash_attn=True drops the temporal mask in the reference (SURVEY 8c); the "
+                                      "masked attention kernel is the only attention path here")
+        return cls(sd, cfg, device)
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def forward(self, sample, encoder_hidden_states=None, encoder_attention_mask=None, pooled_projections=None,
+                timestep_ratio=None):
+        """modeling_pyramid_flux.py:392-399 / modeling_pyramid_mmdit.py:420-427.
+        Reference form: `sample` = List[n_stage] of List[clip [B,C,t,h,w]] (oldest .. current) -> List[n_stage] of
+        the current clip's prediction [B,C,t,h,w] in the dtype of the clips.  Engine form (tests, smoke): `sample` =
+        flat list of clips of ONE stage -> one fp32 tensor."""
+        if len(sample) and isinstance(sample[0], (list, tuple)):
+            outs = []
+            for stage_clips in sample:
+                o = self._forward_stage(stage_clips, encoder_hidden_states, encoder_attention_mask, pooled_projections,
+                                        timestep_ratio)
+                outs.append(o.to(stage_clips[-1].dtype))
+            return outs
+        return self._forward_stage(sample, encoder_hidden_states, encoder_attention_mask, pooled_projections, timestep_ratio)
+
+    def _forward_stage(self, clips, enc, enc_mask, pooled, timesteps):
+        """one pyramid stage: returns [B, C, t, h, w] fp32 of the LAST clip (flux:392-542)."""
         clips = [c.to(self.dev, torch.float32).contiguous() for c in clips]
         shapes = [tuple(c.shape[2:]) for c in clips]
         plan = self.make_plan(shapes, enc_mask)
@@ -436,3 +520,8 @@ class FluxEngine:
         x = vt[:, :, :self.w.out_cols].reshape(B, t, h // 2, w_ // 2, 2, 2, Cc)
         x = x.permute(0, 1, 2, 4, 3, 5, 6).reshape(B, t, h, w_, Cc).permute(0, 4, 1, 2, 3)
         return x.contiguous()
+
+
+# the reference's two transformer classes are one engine here (the variant is read off the state dict)
+PyramidFluxTransformer = FluxEngine       # pyramid_dit/flux_modules/modeling_pyramid_flux.py:60
+PyramidDiffusionMMDiT = FluxEngine        # pyramid_dit/mmdit_modules/modeling_pyramid_mmdit.py:60

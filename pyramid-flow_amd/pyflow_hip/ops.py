@@ -59,14 +59,16 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
     if PROFILER.enabled:      # attribute the launch to the kernel rocprofv3 will name
         bn = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K))
-        name = f"gemm256_kernel<{bn}>" if bn > 0 else (f"gemm256w4_kernel<{-bn}>" if bn < 0 else "gemm_kernel(128x128)")
+        name = "gemm8p_kernel" if bn == 8 else (f"gemm256_kernel<{bn}>" if bn > 0 else (
+            f"gemm256w4_kernel<{-bn}>" if bn < 0 else "gemm_kernel(128x128)"))
     else:
         name = "gemm"
     PROFILER.launch(name, 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
 
 
 def gemm_set_policy(force):
-    """0 auto | -1 128x128 kernel only | 128/192/256 force the 256xBN kernel (pf_gemm_set_policy)."""
+    """0 auto | -1 128x128 kernel only | 128/192/256 force the 256xBN kernel | 8 / -8 force / forbid the persistent
+    256x256 kernel gemm8p (pf_gemm_set_policy)."""
     check(L.load().pf_gemm_set_policy(C.c_int(force)))
 
 

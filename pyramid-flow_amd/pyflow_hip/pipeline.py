@@ -43,7 +43,7 @@ def block_noise_cholesky(gamma):
 
 
 class PyramidDiTForVideoGeneration:
-    def __init__(self, model_path=None, model_dtype="bf16", model_name="pyramid_flux", use_gradient_checkpointing=False,
+    def __init__(self, model_path=None, model_dtype="bf16", model_name="pyramid_mmdit", use_gradient_checkpointing=False,
                  return_log=True, model_variant="diffusion_transformer_768p", timestep_shift=1.0,
                  stage_range=[0, 1 / 3, 2 / 3, 1], sample_ratios=[1, 1, 1], scheduler_gamma=1 / 3,
                  use_mixed_training=False, use_flash_attn=False, load_text_encoder=True, load_vae=True,
@@ -72,7 +72,6 @@ class PyramidDiTForVideoGeneration:
         else:
             self.sp = None
             self.dit = FluxEngine(dit_state_dict, dit_config, device)
-        self.dit.config = type("Cfg", (), dict(dit_config))()
         self.text_encoder = text_encoder
         self.load_text_encoder = load_text_encoder
         if text_encoder is None and load_text_encoder and model_path is not None \
@@ -140,7 +139,6 @@ class PyramidDiTForVideoGeneration:
         sd = self.remap_dit_checkpoint(checkpoint)
         cfg = self.dit.cfg
         self.dit = type(self.dit)(sd, cfg, self._device, **({"comm": self.sp} if self.sp is not None else {}))
-        self.dit.config = type("Cfg", (), dict(cfg))()
         self._plans = {}
         print(f"Load checkpoint from {checkpoint_path}: {len(sd)} tensors re-packed")
 
@@ -427,13 +425,4 @@ class PyramidDiTForVideoGeneration:
                                   output_type=output_type)
 
 
-def _load_diffusers_dir(path):
-    """config.json + diffusion_pytorch_model.safetensors (pipeline.py:73,156)."""
-    from safetensors.torch import load_file
-    with open(os.path.join(path, "config.json")) as f:
-        cfg = json.load(f)
-    sd = {}
-    for fn in sorted(os.listdir(path)):
-        if fn.endswith(".safetensors"):
-            sd.update(load_file(os.path.join(path, fn)))
-    return sd, cfg
+from .refapi import load_diffusers_dir as _load_diffusers_dir  # noqa: E402  (config.json + *.safetensors, pipeline.py:73,156)

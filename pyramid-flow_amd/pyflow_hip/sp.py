@@ -231,22 +231,30 @@ class SPComm:
 
 # ---- reference-named helpers (trainer_misc/sp_utils.py) ---------------------------------------------------------
 _SP = None
+_SP_PROC_NUM = None
 
 
 def init_sequence_parallel_group(args=None, sp_group_size=None):
-    """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world)."""
-    global _SP
+    """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world) over the
+    first `args.sp_proc_num` processes (-1 / absent = all).  A process outside every group stays un-initialised."""
+    global _SP, _SP_PROC_NUM
     world = dist.get_world_size()
     size = sp_group_size or getattr(args, "sp_group_size", None) or world
-    assert world % size == 0
+    proc = getattr(args, "sp_proc_num", -1) if args is not None else -1
+    proc = world if proc in (-1, None) else proc
+    assert proc % size == 0, "The process needs to be evenly divided"
+    _SP_PROC_NUM = proc
     rank = dist.get_rank()
-    group = None
-    if size != world:
-        for g0 in range(0, world, size):
+    group, member = None, False
+    if size == world and proc == world:
+        member = True                                  # the default group
+    else:
+        for g0 in range(0, proc, size):
             grp = dist.new_group(list(range(g0, g0 + size)))
             if g0 <= rank < g0 + size:
-                group = grp
-    _SP = SPComm(group)
+                group, member = grp, True
+    if member:
+        _SP = SPComm(group)
     return _SP
 
 
@@ -264,3 +272,25 @@ def get_sequence_parallel_world_size():
 
 def get_sequence_parallel_rank():
     return _SP.rank if _SP else 0
+
+
+def get_sequence_parallel_group():
+    """sp_utils.py:69-71"""
+    assert _SP is not None, "sequence parallel group is not initialized"
+    return _SP.group if _SP.group is not None else dist.group.WORLD
+
+
+def get_sequence_parallel_group_rank():
+    """sp_utils.py:89-93: index of this process's group = global rank // group size"""
+    assert _SP is not None, "sequence parallel size is not initialized"
+    return dist.get_rank() // _SP.world
+
+
+def get_sequence_parallel_proc_num():
+    return _SP_PROC_NUM
+
+
+def reset_sequence_parallel():
+    """test hook: forget the group (the reference has no teardown; a process normally initialises once)"""
+    global _SP, _SP_PROC_NUM
+    _SP, _SP_PROC_NUM = None, None

@@ -27,6 +27,7 @@ import torch
 
 from . import ops
 from .lib import GEMM_GATE_RES, GEMM_ACT_QUICK_GELU, GEMM_ACT_GELU_ERF
+from .refapi import DeviceModuleAPI
 
 
 def _cfg_get(cfg, key, default=None):
@@ -273,7 +274,7 @@ def _tokenizers(model_path, names):
     return out
 
 
-class _TextEncoderBase:
+class _TextEncoderBase(DeviceModuleAPI):
     T5_MAX_LEN = 128              # modeling_text_encoder.py:39 (flux) / :43 (mmdit)
 
     def _t5(self, prompt, device, num_images_per_prompt=1):
@@ -311,6 +312,7 @@ class FluxTextEncoderWithMask(_TextEncoderBase):
             tokenizer, tokenizer_2 = _tokenizers(model_path, [("tokenizer", "clip"), ("tokenizer_2", "t5")])
             clip = CLIPTextHIP(*_load_dir(os.path.join(model_path, "text_encoder")), device=device)
             t5 = T5EncoderHIP(*_load_dir(os.path.join(model_path, "text_encoder_2")), device=device)
+        self.dev = torch.device(getattr(t5, "dev", device))
         self.tokenizer, self.text_encoder = tokenizer, clip
         self.t5_tokenizer, self.t5 = tokenizer_2, t5
         self.tokenizer_2, self.text_encoder_2 = tokenizer_2, t5
@@ -335,6 +337,7 @@ class SD3TextEncoderWithMask(_TextEncoderBase):
             clip = CLIPTextHIP(*_load_dir(os.path.join(model_path, "text_encoder")), device=device)
             clip_2 = CLIPTextHIP(*_load_dir(os.path.join(model_path, "text_encoder_2")), device=device)
             t5 = T5EncoderHIP(*_load_dir(os.path.join(model_path, "text_encoder_3")), device=device)
+        self.dev = torch.device(getattr(t5, "dev", device))
         self.tokenizer, self.text_encoder = tokenizer, clip
         self.tokenizer_2, self.text_encoder_2 = tokenizer_2, clip_2
         self.tokenizer_3, self.text_encoder_3 = tokenizer_3, t5

@@ -19,6 +19,7 @@ from . import lib as L
 from . import ops
 from .lib import ConvDesc, check, stream, GEMM_GATE_RES
 
+from .refapi import DeviceModuleAPI, load_diffusers_dir  # noqa: E402
 
 def _ru(x, m):
     return (x + m - 1) // m * m
@@ -435,7 +436,7 @@ class DecoderOutput:
         self.sample = sample
 
 
-class CausalVideoVAE:
+class CausalVideoVAE(DeviceModuleAPI):
     """decode(z, is_init_image=True, temporal_chunk=False, return_dict=True, window_size=2, tile_sample_min_size=256)
     -> DecoderOutput(sample [B,3,T,H,W]);  enable_tiling()/disable_tiling()  (modeling_causal_vae.py:183-196, 376-395)."""
 
@@ -505,6 +506,18 @@ class CausalVideoVAE:
         # (a few GB per tile program at 768p); 1 = the reference's schedule literally.
         self.chunk_coalesce = 4
         self._streams = []
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, torch_dtype=None, device="cuda", interpolate=False, **kwargs):
+        """pipeline.py:156: `CausalVideoVAE.from_pretrained(os.path.join(model_path, 'causal_video_vae'),
+        torch_dtype=, interpolate=False)` -- config.json + safetensors directory"""
+        sd, cfg = load_diffusers_dir(pretrained_model_path)
+        return cls(sd, cfg, device)
+
+    @property
+    def config(self):
+        import types
+        return types.SimpleNamespace(**dict(self.cfg_in or self.cfg))
 
     def enable_tiling(self, use_tiling=True):
         self.use_tiling = use_tiling

@@ -1,0 +1,149 @@
+"""GPU parity of the persistent 256 x 256 / 16x16x32 GEMM kernel (gemm8p.hip) against torch fp32, forced through
+pf_gemm_set_policy(8) so that small shapes reach it too: M / N tails, batches, every epilogue flavour (bias, GELU
+from a column, gate*x+res, fp32 output), K-tile counts 1..5 (prologue / drain of the operand stream), more tiles than
+workgroups (the stream crossing tile boundaries), and the implicit-GEMM conv path through a VAE decode."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+@pytest.fixture
+def policy8():
+    from pyflow_hip import ops
+    ops.gemm_set_policy(8)
+    yield
+    ops.gemm_set_policy(0)
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (256, 256, 64), (256, 256, 128), (700, 384, 192), (77, 576, 128), (513, 512, 256), (3000, 256, 640),
+    (2048 + 5, 1920, 320), (700, 5760, 128), (300, 328, 192), (1024, 13440, 64), (600, 384, 7680), (520, 512, 9600),
+    (5120 + 7, 2688, 192), (4100, 4352, 128), (16384 + 3, 2304, 64), (70000, 256, 64),      # > 256 tiles per launch
+    (30976, 1920, 1920),
+])
+def test_gemm8p_bias(policy8, M, N, K):
+    from pyflow_hip import ops
+    assert ops.L.load().pf_gemm_which(M, 1, N, K) == 8
+    A = _mk((M, K), 1).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 2, 0.05).to(torch.bfloat16).to(DEV)
+    W[0, :] += 1.0          # asymmetric: a transposed C write cannot pass
+    bias = _mk((N,), 3).to(DEV)
+    C = torch.zeros(M + 3, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, W, C, M, N, K, K, K, N, bias=bias)
+    ref = A.float() @ W.float().T + bias
+    assert rel_l2(C[:M].float(), ref) < 5e-3
+    assert (C[:M].float() - ref).abs().max() <= 2 ** -6 * ref.abs().max()
+    assert C[M:].abs().max() == 0          # rows beyond M untouched
+
+
+def test_gemm8p_identity_layout(policy8):
+    """every (row, column) lands where it belongs: the W-row permutation of the DMA and the C^T accumulators undo each other"""
+    from pyflow_hip import ops
+    M, N, K = 768, 512, 768
+    A = torch.eye(M, dtype=torch.bfloat16, device=DEV)[:, :K].contiguous()
+    W = (torch.arange(N)[:, None] * 0.5 + torch.arange(K)[None, :] * 0.001).to(torch.bfloat16).to(DEV)
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, W, C, M, N, K, K, K, N)
+    assert torch.equal(C.float(), W.float().T.contiguous())
+
+
+@pytest.mark.parametrize("d", [256, 384, 1920])
+def test_gemm8p_batched_strided_gelu_gate(policy8, d):
+    from pyflow_hip import ops
+    B, Lr = 2, 600
+    L = Lr + 16
+    x = _mk((B, L, d), 4).to(torch.bfloat16).to(DEV)
+    W = _mk((2 * d, d), 5, 0.06).to(torch.bfloat16).to(DEV)
+    bias = _mk((2 * d,), 6, 0.1).to(DEV)
+    out = torch.zeros(B, L, 2 * d, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, W, out, Lr, 2 * d, d, d, d, 2 * d, bias=bias, batch=B, strideA=L * d, strideC=L * 2 * d,
+             gelu_from=d, a_off=16 * d, c_off=16 * 2 * d)
+    ref = x[:, 16:].float() @ W.float().T + bias
+    ref[..., d:] = F.gelu(ref[..., d:], approximate="tanh")
+    assert rel_l2(out[:, 16:].float(), ref) < 5e-3
+    assert out[:, :16].abs().max() == 0
+    hid = _mk((B, L, d), 7).to(torch.bfloat16).to(DEV)
+    hid0 = hid.clone()
+    W2 = _mk((d, 2 * d), 8, 0.05).to(torch.bfloat16).to(DEV)
+    b2 = _mk((d,), 9, 0.1).to(DEV)
+    gate = _mk((B, 3 * d), 10).to(DEV)
+    ops.gemm(out, W2, hid, Lr, d, 2 * d, 2 * d, 2 * d, d, bias=b2, res=hid, gate=gate, gate_off=d, ldr=d, batch=B,
+             strideA=L * 2 * d, strideC=L * d, strideR=L * d, gate_stride=3 * d, flags=ops.GEMM_GATE_RES,
+             a_off=16 * 2 * d, c_off=16 * d, r_off=16 * d)
+    ref2 = hid0[:, 16:].float() + gate[:, None, d:2 * d] * (out[:, 16:].float() @ W2.float().T + b2)
+    assert rel_l2(hid[:, 16:].float(), ref2) < 5e-3
+    assert torch.equal(hid[:, :16], hid0[:, :16])
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 5, 37])
+@pytest.mark.parametrize("M", [256, 1024, 66000])
+def test_gemm8p_short_k_and_f32_out(policy8, nk, M):
+    """prologue / drain paths of the operand stream (1..5 K-tiles, 1 / 1 / 2 tiles per workgroup) and an odd count"""
+    from pyflow_hip import ops
+    N, K = 256, 64 * nk
+    A = _mk((M, K), 20 + nk).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 30 + nk, 0.1).to(torch.bfloat16).to(DEV)
+    C = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A, W, C, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32)
+    assert rel_l2(C, A.float() @ W.float().T) < 1e-5
+
+
+def test_gemm8p_repeatable_and_matches_older_kernels(policy8):
+    """same fp32 accumulation class as the other kernels; bitwise repeatable (no split-K, no atomics)"""
+    from pyflow_hip import ops
+    M, N, K = 4096, 768, 1920
+    A = _mk((M, K), 41).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 42, 0.03).to(torch.bfloat16).to(DEV)
+    C1 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    C2 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A, W, C1, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32)
+    ops.gemm(A, W, C2, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32)
+    assert torch.equal(C1, C2)
+    ops.gemm_set_policy(-1)
+    C3 = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm(A, W, C3, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32)
+    assert rel_l2(C1, C3) < 1e-6
+
+
+def test_gemm8p_stress_many_launches(policy8):
+    """race screen: the same launch 30 times on fresh outputs must give identical bits (LDS hand-offs by counted waits)"""
+    from pyflow_hip import ops
+    M, N, K = 30976, 1920, 1920
+    A = _mk((M, K), 51).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 52, 0.02).to(torch.bfloat16).to(DEV)
+    ref = None
+    for i in range(30):
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(A, W, C, M, N, K, K, K, N)
+        if ref is None:
+            ref = C
+            assert rel_l2(C[:4096].float(), A[:4096].float() @ W.float().T) < 5e-3
+        else:
+            assert torch.equal(C, ref), i
+
+
+def test_vae_decode_with_gemm8p(policy8):
+    """implicit-GEMM conv path (tap walk of the operand stream, pixel-shuffle / depth-to-time store maps, shortcut add)"""
+    from pyflow_hip import synth
+    from pyflow_hip.vae import CausalVideoVAE
+    from oracle.vae_oracle import vae_decode
+    from util import round_sd
+    cfg = synth.TINY_VAE
+    sd = round_sd(synth.random_state_dict(synth.vae_decoder_param_shapes(cfg), seed=5, std=0.05, lively=True))
+    z = torch.randn(1, 16, 3, 6, 10, generator=torch.Generator().manual_seed(2))
+    ocfg = dict(decoder_block_out_channels=cfg["block_out_channels"], decoder_layers_per_block=cfg["layers_per_block"],
+                decoder_spatial_up_sample=cfg["spatial_up_sample"], decoder_temporal_up_sample=cfg["temporal_up_sample"])
+    ref = vae_decode(sd, ocfg, z)
+    vae = CausalVideoVAE(sd, cfg, "cuda")
+    out = vae.decode(z.cuda(), temporal_chunk=True, window_size=1).sample.float().cpu()
+    assert rel_l2(out, ref) < 2e-2
