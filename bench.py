@@ -27,13 +27,19 @@ WORKLOADS = {
     # config C4: SD3-style MMDiT image-to-video, VAE encode + decode in the loop (generate_i2v, temp 16 -> 121 frames)
     "c4_i2v_768p_121f": (768, 1280, 16, [10, 10, 10], [10, 10, 10]),
     "c2_384p_121f": (384, 640, 16, [20, 20, 20], [10, 10, 10]),
+    # config C1: miniFLUX 1024 x 1024 single image, ONE pyramid stage, 20 steps, guidance 9
+    "c1_1024p_image": (1024, 1024, 1, [20], [20]),
+    # config C5: standalone CausalVideoVAE decode of a 768p 241-frame latent (no DiT): the reference's tiled(256) /
+    # chunked(1) schedule on one GPU; with N GPUs the temporal context-parallel decode (un-tiled, halo exchange per
+    # causal conv) when a rank's frame range fits in HBM, otherwise the tile-parallel form of the tiled decode
+    "c5_vae_768p_241f": (768, 1280, 31, None, None),
     "smoke_128p_17f": (128, 192, 3, [4, 4, 4], [2, 2, 2]),
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E (same guide)
 
 
-def build_pipeline(device, tiny=False, mmdit=False):
+def build_pipeline(device, tiny=False, mmdit=False, stages=None):
     from pyflow_hip import synth
     from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
     if mmdit:
@@ -65,7 +71,8 @@ def build_pipeline(device, tiny=False, mmdit=False):
         vcfg.update(ecfg)
     pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=dcfg, vae_state_dict=vsd, vae_config=vcfg,
                                         model_name="pyramid_mmdit" if mmdit else "pyramid_flux", model_dtype="bf16",
-                                        device=device)
+                                        device=device, **(dict(stages=[1], stage_range=[0, 1], sample_ratios=[1])
+                                                          if stages == 1 else {}))
     pipe.vae.enable_tiling()                      # reference inference setup (inference_multigpu.py:52-55)
     return pipe, dcfg, dsd
 
@@ -108,13 +115,35 @@ class SampledProfiler:
         self.active = False
 
 
+def c3_schedule():
+    """(L, forwards) of every (unit, stage) of the headline job: 768p, temp 31, steps [20]*3 / [10]*3, text 128
+    (sequence = [text | history clips | current frame])."""
+    tok = [240, 960, 3840]                       # tokens per latent frame at stage 0, 1, 2
+    out = []
+    for u in range(31):
+        for s_ in range(3):
+            # frame u-1 at the stage's resolution, frame u-2 one stage lower, everything older at stage 0
+            hist = (tok[s_] if u >= 1 else 0) + (tok[max(s_ - 1, 0)] if u >= 2 else 0) + max(u - 2, 0) * tok[0]
+            out.append((128 + hist + tok[s_], 20 if u == 0 else 10))
+    return out
+
+
 def cpu_baseline(dcfg, dsd, threads):
-    """reference path (CPU fp32 oracle restatement, kind 'port') on a BOUNDED sample: one double-stream + one
-    single-stream miniFLUX block at full width (d = 1920, 30 heads) inside a complete forward (embedders, conditioning,
-    RoPE, masked SDPA, norm_out/proj_out) at the (unit 1, stage 0) sequence (L = 608, CFG batch 2); timed, then
-    extrapolated to the whole 241-frame job by the dense-FLOP ratio of SURVEY 8d (50.67 PFLOP DiT; VAE decode and the
-    host loop are not added, which flatters the CPU)."""
+    """The reference path on the host cores, SURVEY 8d recipe, kind "port": the CPU fp32 oracle restatement (oracle/,
+    pinned to the imported reference in the dev container) -- /root/reference itself does not exist on the GPU box, so
+    the reference cannot be imported where this runs.  Bounded sample (~20 s of CPU work):
+      * one double-stream + one single-stream miniFLUX block at full width (d = 1920, 30 heads, CFG batch 2) inside a
+        complete oracle forward at five sequence lengths of the schedule (unit 0 stages 0-2, unit 1 stages 0-1);
+        t(L) = a L + b L^2 is fitted (GEMM / attention terms), residuals reported, and summed over the 960 forwards of
+        the job x 12 (24 blocks = 12 x the sampled pair);
+      * one VAE tile-chunk: a 32 x 32 latent tile, one latent frame, full channel widths -> scaled to 28 tiles x 241
+        output frames (first-chunk cost per output frame);
+      * the reference's per-block Python sampling loop of the block noise (pipeline.py:697-703): 2 000 draws timed,
+        scaled to the 76 800 draws of each of the 30 video units."""
+    import numpy as np
     from oracle.flux_oracle import flux_forward
+    from oracle.vae_oracle import vae_decode
+    from pyflow_hip import synth
     threads = max(1, min(threads, 64))          # beyond ~64 threads the CPU GEMMs of this size slow down
     torch.set_num_threads(threads)
     cfg = dict(dcfg, num_layers=1, num_single_layers=1)
@@ -122,30 +151,62 @@ def cpu_baseline(dcfg, dsd, threads):
           if not (k.startswith("transformer_blocks.") and not k.startswith("transformer_blocks.0."))
           and not (k.startswith("single_transformer_blocks.") and not k.startswith("single_transformer_blocks.0."))}
     g = torch.Generator().manual_seed(9)
-    clips = [torch.randn(2, 16, 1, 24, 40, generator=g), torch.randn(2, 16, 1, 24, 40, generator=g)]
     enc = torch.randn(2, 128, dcfg["joint_attention_dim"], generator=g)
     mask = torch.zeros(2, 128, dtype=torch.long)
     mask[0, :40] = 1
     mask[1, :96] = 1
     pooled = torch.randn(2, dcfg["pooled_projection_dim"], generator=g)
+    points = {368: [(1, 24, 40)], 608: [(1, 24, 40), (1, 24, 40)], 1088: [(1, 48, 80)],
+              2048: [(1, 48, 80), (1, 48, 80)], 3968: [(1, 96, 160)]}
+    meas = []
+    t_budget = time.time()
     with torch.no_grad():
-        flux_forward(sd, cfg, clips, enc, mask, pooled, torch.tensor([900.0, 900.0]))      # warm-up (allocator, threads)
+        for L, shapes in points.items():
+            clips = [torch.randn(2, 16, *s_, generator=g) for s_ in shapes]
+            ts_ = torch.tensor([900.0, 900.0])
+            flux_forward(sd, cfg, clips, enc, mask, pooled, ts_)          # warm-up (allocator, threads)
+            reps, t0 = 0, time.time()
+            while reps < 8 and (reps == 0 or time.time() - t0 < 2.5):
+                flux_forward(sd, cfg, clips, enc, mask, pooled, ts_)
+                reps += 1
+            meas.append((L, (time.time() - t0) / reps))
+    Ls = np.array([m[0] for m in meas], dtype=np.float64)
+    tt = np.array([m[1] for m in meas], dtype=np.float64)
+    A = np.stack([Ls, Ls * Ls], axis=1)
+    coef, *_ = np.linalg.lstsq(A, tt, rcond=None)
+    resid = (A @ coef - tt) / tt
+    dit_s = sum(n * max(coef[0] * L + coef[1] * L * L, 0.0) for L, n in c3_schedule()) * 12.0
+    # VAE tile-chunk
+    vcfg = synth.VAE_DEFAULT
+    vshapes = synth.vae_decoder_param_shapes(vcfg)
+    gv = torch.Generator().manual_seed(10)
+    vsd = {k: (torch.ones(sh) if k.endswith(".weight") else torch.zeros(sh)) if len(sh) == 1
+           else torch.randn(sh, generator=gv) * 0.02 for k, sh in vshapes.items()}
+    ocfg = dict(decoder_block_out_channels=vcfg["block_out_channels"], decoder_layers_per_block=vcfg["layers_per_block"],
+                decoder_spatial_up_sample=vcfg["spatial_up_sample"], decoder_temporal_up_sample=vcfg["temporal_up_sample"])
+    z = torch.randn(1, 16, 1, 32, 32, generator=gv)
+    with torch.no_grad():
         t0 = time.time()
-        reps = 0
-        while reps < 40 and (reps == 0 or time.time() - t0 < 12.0):
-            flux_forward(sd, cfg, clips, enc, mask, pooled, torch.tensor([900.0, 900.0]))
-            reps += 1
-    dt = (time.time() - t0) / reps
-    d = dcfg["num_attention_heads"] * dcfg["attention_head_dim"]
-    L, B = 608, 2
-    nblk = 2
-    sample_flops = 2 * B * L * 12 * d * d * nblk + 4 * B * L * L * d * nblk
-    total_dense = 50.67e15
-    est_seconds = dt * total_dense / sample_flops
-    return dict(value=241.0 / est_seconds, unit="frames/s", cores=threads, kind="port",
-                sample=f"{reps} x (1 double + 1 single miniFLUX block at full width inside a complete oracle forward (L=608, B=2), "
-                       f"{sample_flops / 1e12:.3f} TFLOP of block work each, mean {dt:.2f} s = {sample_flops / dt / 1e12:.3f} TFLOP/s fp32 on "
-                       f"{threads} threads; extrapolated to the 50.67 PFLOP dense DiT work of one 241-frame video (VAE decode not added)")
+        vae_decode(vsd, ocfg, z)
+        t_tile = time.time() - t0
+    vae_s = t_tile * 28 * 241
+    # block-noise loop of the reference (per-block MultivariateNormal.sample() in Python)
+    gamma = 1.0 / 3.0
+    dist_ = torch.distributions.multivariate_normal.MultivariateNormal(
+        torch.zeros(4), torch.eye(4) * (1 + gamma) - torch.ones(4, 4) * gamma, validate_args=False)
+    t0 = time.time()
+    for _ in range(2000):
+        dist_.sample()
+    noise_s = (time.time() - t0) / 2000 * (15360 + 61440) * 30
+    est = dit_s + vae_s + noise_s
+    return dict(value=241.0 / est, unit="frames/s", cores=threads, kind="port",
+                sample=("oracle (CPU fp32 restatement of the reference; /root/reference is absent on the GPU box) on "
+                        f"{threads} threads, {time.time() - t_budget:.0f} s of CPU work: 1 double + 1 single miniFLUX block at "
+                        f"full width inside a complete forward at L = {[m[0] for m in meas]} -> {[round(m[1], 3) for m in meas]} s; "
+                        f"fit t = {coef[0]:.3e} L + {coef[1]:.3e} L^2 (relative residuals {[round(float(r), 3) for r in resid]}), "
+                        f"summed over the 960 forwards x 12 = {dit_s:.0f} s DiT; one 32x32x1-latent VAE tile-chunk {t_tile:.2f} s "
+                        f"x 28 tiles x 241 frames = {vae_s:.0f} s; reference block-noise Python loop {noise_s:.0f} s; "
+                        f"total {est:.0f} s per 241-frame video"))
 
 
 def main():
@@ -195,25 +256,65 @@ def main():
 
     H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
     i2v = args.workload.startswith("c4")
-    pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model, mmdit=i2v)
-    embeds = synthetic_prompt(dcfg, device)
-    image = torch.randn(3, H, W, generator=torch.Generator().manual_seed(77)).clamp(-1, 1)
-    sp = SampledProfiler(pipe, args.profile_period)
+    image_only = args.workload.startswith("c1")
+    vae_only = args.workload.startswith("c5")
     frames_per_video = 1 + 8 * (temp - 1)
+    from pyflow_hip import video_io
+    pinned = torch.empty(frames_per_video * H * W * 3, dtype=torch.uint8).pin_memory() if (rank == 0 or not use_sp) else None
 
-    def one_video(seed):
-        if i2v:
-            return pipe.generate_i2v(prompt_embeds=embeds, input_image=image, temp=temp, num_inference_steps=stepsv,
-                                     guidance_scale=7.0, video_guidance_scale=4.0,
-                                     generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
-        return pipe.generate(prompt_embeds=embeds, height=H, width=W, temp=temp, num_inference_steps=steps1,
-                             video_num_inference_steps=stepsv, guidance_scale=7.0, video_guidance_scale=5.0,
-                             generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
+    def to_host(u8):
+        # the metric ends with the uint8 frames in HOST memory: pinned-buffer D2H inside the timed region
+        return None if u8 is None else video_io.frames_to_host(u8, pinned)
 
-    # lazy code-object loading / first allocations are initialisation, not a step
-    pipe.generate(prompt_embeds=embeds, height=64, width=64, temp=2, num_inference_steps=[1, 1, 1],
-                  video_num_inference_steps=[1, 1, 1], guidance_scale=7.0, video_guidance_scale=5.0,
-                  generator=torch.Generator().manual_seed(0), output_type="uint8")
+    if vae_only:
+        # ---- config C5: standalone decode of a synthetic 768p latent
+        from pyflow_hip import synth
+        from pyflow_hip.vae import CausalVideoVAE
+        g = torch.Generator(device=device).manual_seed(1234)
+        vcfg = synth.TINY_VAE if args.tiny_model else synth.VAE_DEFAULT
+        vsd = {k: (torch.ones(sh, device=device) if k.endswith(".weight") else torch.zeros(sh, device=device)) if len(sh) == 1
+               else torch.randn(sh, generator=g, device=device) * 0.02 for k, sh in synth.vae_decoder_param_shapes(vcfg).items()}
+        vae = CausalVideoVAE(vsd, vcfg, device)
+        vae.enable_tiling()
+        z = torch.randn(1, 16, temp, H // 8, W // 8, generator=torch.Generator().manual_seed(5)).to(device)
+        comm = sp_mod.get_sequence_parallel_comm() if use_sp else None
+        # un-tiled temporal context parallelism needs every full-resolution activation of a rank's frame range resident:
+        # ~8 live buffers of (8 x frames) x 770 x 1282 x 256 ch bf16 at the widest level
+        cp_bytes = 8 * (8 * -(-temp // max(world, 1))) * (H + 2) * (W + 2) * 256 * 2
+        use_cp = use_sp and -(-temp // world) >= 2 and temp // world >= 2 and cp_bytes < 0.7 * torch.cuda.get_device_properties(0).total_memory
+        dcfg, dsd, pipe, sp = None, None, None, None
+
+        def one_video(seed):
+            if use_cp:
+                return to_host(vae.decode_context_parallel(z, comm))
+            return to_host(vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256, comm=comm))
+        vae.decode_to_uint8(torch.randn(1, 16, 2, 8, 8, device=device), window_size=1, tile_sample_min_size=256)
+    else:
+        pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model, mmdit=i2v, stages=1 if image_only else None)
+        embeds = synthetic_prompt(dcfg, device)
+        image = torch.randn(3, H, W, generator=torch.Generator().manual_seed(77)).clamp(-1, 1)
+        sp = SampledProfiler(pipe, args.profile_period)
+
+        def one_video(seed):
+            if i2v:
+                u8 = pipe.generate_i2v(prompt_embeds=embeds, input_image=image, temp=temp, num_inference_steps=stepsv,
+                                       guidance_scale=7.0, video_guidance_scale=4.0,
+                                       generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
+            elif image_only:
+                u8 = pipe.generate(prompt_embeds=embeds, height=H, width=W, temp=1, num_inference_steps=steps1,
+                                   video_num_inference_steps=stepsv, guidance_scale=9.0, video_guidance_scale=5.0,
+                                   generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
+            else:
+                u8 = pipe.generate(prompt_embeds=embeds, height=H, width=W, temp=temp, num_inference_steps=steps1,
+                                   video_num_inference_steps=stepsv, guidance_scale=7.0, video_guidance_scale=5.0,
+                                   generator=torch.Generator().manual_seed(seed), output_type="uint8", save_memory=True)
+            return to_host(u8)
+
+        # lazy code-object loading / first allocations are initialisation, not a step
+        pipe.generate(prompt_embeds=embeds, height=64, width=64, temp=1 if image_only else 2,
+                      num_inference_steps=[1] * len(pipe.stages), video_num_inference_steps=[1] * len(pipe.stages),
+                      guidance_scale=7.0, video_guidance_scale=5.0, generator=torch.Generator().manual_seed(0),
+                      output_type="uint8")
     for i in range(args.warmup):
         one_video(100 + i)
 
@@ -223,15 +324,17 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    sp.active = True
+    if sp is not None:
+        sp.active = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_video(i)
     barrier()
     dt = time.perf_counter() - t0
-    sp.active = False
+    if sp is not None:
+        sp.active = False
     if rank == 0 or not use_sp:
-        assert out.shape == (frames_per_video, H, W, 3) and out.dtype == torch.uint8
+        assert out.shape == (frames_per_video, H, W, 3) and out.dtype == torch.uint8 and not out.is_cuda
     else:
         assert out is None
     if world > 1:
@@ -256,19 +359,22 @@ def main():
     dom = max(recs, key=lambda n: recs[n]["ms_timed"]) if recs else None
     roof = recs.pop(dom) if dom else None
     extra = recs
+    if vae_only:
+        roof, extra = None, {}
     # VAE decode kernels: one full 256 x 256 tile (5 latent frames -> 33 frames, the launch shapes of the timed decode) is
     # decoded once more AFTER the timed region on a single stream with the per-launch profiler on: implicit-GEMM convs
     # against the MFMA peak, GroupNorm + SiLU passes against the HBM peak (SURVEY 8d asks for both)
     try:
-        if pipe.vae is not None:
+        the_vae = vae if vae_only else pipe.vae
+        if the_vae is not None:
             ops.PROFILER.records = {}
-            keep_ns, pipe.vae.n_streams = pipe.vae.n_streams, 1
+            keep_ns, the_vae.n_streams = the_vae.n_streams, 1
             zt = torch.randn(1, 16, 5, 32, 32, device=device)
-            pipe.vae.decode_to_uint8(zt, window_size=1, tile_sample_min_size=256)       # allocations / first launches
+            the_vae.decode_to_uint8(zt, window_size=1, tile_sample_min_size=256)       # allocations / first launches
             ops.PROFILER.enabled = True
-            pipe.vae.decode_to_uint8(zt, window_size=1, tile_sample_min_size=256)
+            the_vae.decode_to_uint8(zt, window_size=1, tile_sample_min_size=256)
             ops.PROFILER.enabled = False
-            pipe.vae.n_streams = keep_ns
+            the_vae.n_streams = keep_ns
             torch.cuda.synchronize()
             for name, sv in ops.PROFILER.summary().items():
                 if sv["ms_total"] <= 0 or name not in ("conv3d", "gn_stats", "gn_apply"):
@@ -310,7 +416,9 @@ def main():
         "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling",
         "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True,
-        "scaling": "strong" if use_sp else "weak",
+        # N > 1 default: ONE video over all GPUs (total work fixed) = strong scaling; the N = 1 line of the same sweep says
+        # the same; `--parallelism replicas` is the weak-scaling form
+        "scaling": "strong" if (args.parallelism == "sp" and (use_sp or world == 1)) else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: miniFLUX pyramid DiT (1.97 B params, 8+16 blocks, d=1920) + CausalVideoVAE "
                                f"tiled(256)/chunked(1) decode (the reference's save_memory schedule; four chunk windows per launch set), {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
@@ -328,7 +436,24 @@ def main():
         res["config"]["workload"] = (f"{args.workload}: SD3-style MMDiT (24 joint blocks, d=1536) generate_i2v + CausalVideoVAE "
                                      f"tiled encode / decode, {H}x{W}, temp={temp} ({frames_per_video} frames), steps {stepsv}, "
                                      "CFG 7.0/4.0, random-init weights, synthetic prompt embeddings and image")
-    if not args.no_cpu_baseline and world == 1 and not args.tiny_model and not i2v:
+    if image_only:
+        res["metric"] = "images/sec for 1024x1024 one-stage text-to-image sampling (config C1, not the headline metric)"
+        res["unit"] = "images/s"
+        res["config"]["workload"] = (f"{args.workload}: miniFLUX, ONE pyramid stage (stages=[1], stage_range=[0,1]), {H}x{W}, "
+                                     f"{steps1[0]} steps, CFG 9.0, L = 4 224 tokens per forward, tiled VAE decode, random-init "
+                                     "weights, synthetic prompt embeddings")
+    if vae_only:
+        res["metric"] = "video frames/sec for standalone 768p 241-frame CausalVideoVAE decode (config C5, not the headline metric)"
+        res["config"]["workload"] = (f"{args.workload}: CausalVideoVAE decode of a synthetic latent [1,16,{temp},{H // 8},{W // 8}] -> "
+                                     f"{frames_per_video} uint8 frames in host memory; "
+                                     + ("temporal context-parallel un-tiled decode (halo exchange per causal conv, uneven frame ranges)"
+                                        if (vae_only and use_cp) else "tiled(256) / chunked(1) decode, four chunk windows per launch set"
+                                        + (", tile columns split over the ranks" if world > 1 else "")))
+        conv = extra.get("vae:conv3d") or {}
+        res["roofline"] = dict(conv, note="dominant kernel family of the decode: implicit-GEMM CausalConv3d (MFMA-bound for C >= 128); "
+                                          "GroupNorm passes against the HBM peak in roofline_other_kernels") if conv else None
+        res["roofline_other_kernels"] = {k: v for k, v in extra.items() if k != "vae:conv3d"}
+    if not args.no_cpu_baseline and world == 1 and not args.tiny_model and not i2v and not image_only and not vae_only:
         res["cpu_baseline"] = cpu_baseline(dcfg, dsd, os.cpu_count() or 1)
     print(json.dumps(res))
 

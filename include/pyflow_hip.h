@@ -50,14 +50,15 @@ typedef struct {
     int gate_stride, batch, gelu_from, flags;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
-/* Kernel selection for pf_gemm_bf16 / pf_conv3d_bf16 (tuning / test hook; results are identical up to fp32
- * summation order).  0 = automatic (256 x BN ping-pong kernel for large problems whose N is a multiple of 192 or
- * 256, the 128 x 128 kernel otherwise), -1 = always the 128 x 128 kernel, 128/192/256 = force the 256 x BN kernel
- * whenever BN divides N.  Default 0, or the PF_GEMM256 environment variable. */
+/* Kernel selection for pf_gemm_bf16 / pf_conv3d_bf16 (test hook; results are identical up to fp32 summation order).
+ * 0 = automatic: the persistent 256 x 256 kernel (gemm8p) for problems of >= 192 such tiles whose N tail wastes < 7 %,
+ * else the 256 x BN ping-pong kernel (BN = 256 / 192 / 128) when it yields >= 192 tiles, else the 128 x 128 kernel;
+ * -1 = always the 128 x 128 kernel; 128 / 192 / 256 = force the 256 x BN kernel whenever BN divides N;
+ * 8 = force gemm8p whenever its epilogue flavour exists (bias + ONE of residual / fp32 output / GELU-tanh); -8 = never
+ * gemm8p.  Default 0. */
 int pf_gemm_set_policy(int force);
-/* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), BN > 0 =
- * gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN> (the 4-wave form, pf_gemm_set_variant(3)) -- lets a profiler attribute
- * launches to the kernel names rocprofv3 reports */
+/* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =
+ * gemm8p_kernel, BN > 0 = gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */
 int pf_gemm_which(int M, int batch, int N, int K);
 
 /* ------------------------------------------------------------------ CausalConv3d ----------------
@@ -227,6 +228,31 @@ typedef struct {
     int causal; float scale;
 } pf_attn_small_desc;
 int pf_attention_small_bf16(const pf_attn_small_desc* d, pf_stream_t stream);
+
+/* ------------------------------------------------------------------ multi-GPU communicator --------
+ * RCCL over xGMI, one process per GPU.  Replaces the torch.distributed calls of the reference's multi-GPU paths:
+ * dist.all_to_all in trainer_misc/communicate.py:7-26 (sequence parallelism, pf_all_to_all_v), the isend/irecv halo
+ * pass and the list all_gather of video_vae/context_parallel_ops.py:41-114 (context parallelism: pf_halo_send_recv,
+ * pf_all_gather_v), the velocity-token sum / input broadcast that stand in for
+ * pyramid_dit_for_video_gen_pipeline.py:752-756 (pf_all_reduce_sum_f32, pf_broadcast_bytes).
+ * Bootstrap like ncclCommInitRank: ONE rank calls pf_comm_unique_id and ships the 128 bytes to the others by any
+ * channel; every rank then calls pf_comm_init(rank, world, id).  Collectives run on the communicator's own HIP stream,
+ * ordered after the work already queued on `compute` (event); pf_comm_wait(c, s) makes stream s wait for them on the
+ * device.  Counts / offsets are in BYTES and indexed by peer rank; zero counts are allowed (uneven head maps). */
+typedef struct pf_comm pf_comm;
+int pf_comm_unique_id(void* out128);
+int pf_comm_init(pf_comm** out, int rank, int world, const void* unique_id_128);
+int pf_comm_destroy(pf_comm* c);
+int pf_comm_rank(const pf_comm* c);
+int pf_comm_world(const pf_comm* c);
+int pf_all_to_all_v(pf_comm* c, const void* send, const long long* send_bytes, const long long* send_offs, void* recv,
+                    const long long* recv_bytes, const long long* recv_offs, pf_stream_t compute);
+int pf_halo_send_recv(pf_comm* c, const void* send, void* recv, long long bytes, pf_stream_t compute);
+int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const long long* bytes, const long long* offs,
+                    pf_stream_t compute);
+int pf_all_reduce_sum_f32(pf_comm* c, float* buf, long long count, pf_stream_t compute);
+int pf_broadcast_bytes(pf_comm* c, void* buf, long long bytes, int root, pf_stream_t compute);
+int pf_comm_wait(pf_comm* c, pf_stream_t stream);
 
 #ifdef __cplusplus
 }

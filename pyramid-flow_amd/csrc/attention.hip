@@ -15,7 +15,6 @@
 // because the contraction-slot -> key permutation of the C layout is mirrored in the V^T image
 // (pf_v_transpose writes keys permuted within groups of 16).  K and V^T tiles arrive by LDS-DMA
 // with source-side XOR swizzle, double-buffered, one barrier per KV tile.
-#include <stdlib.h>
 #include "common.h"
 #include "pyflow_hip.h"
 
@@ -349,17 +348,12 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.sc = d->scale * 1.4426950408889634f;
     a.hs_qk = d->head_stride_qk > 0 ? d->head_stride_qk : HD;
     if (a.hs_qk % 8) return pf_set_err("pf_attention_bf16: head_stride_qk must be a multiple of 8");
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("PF_ATTN_PRIO"); prio = e ? atoi(e) : 1; }
-    a.prio = prio;
+    a.prio = 1;              // s_setprio around the MFMA groups (measured best of {none, MFMA, softmax}: profiles/r01_attention_variants.log)
     a.qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
     if (a.qt0 >= a.nqt) return pf_set_err("pf_attention_bf16: q_row_begin beyond the sequence");
     const int grid = (a.nqt - a.qt0) * a.H * a.B;
-    static int var = -1;      // tuning hook PF_ATTN_VAR: 0 = 1 chain / 3 waves per SIMD, 1 = 2 chains / 3, 2 = 4 chains / 2
-    if (var < 0) { const char* e = getenv("PF_ATTN_VAR"); var = e ? atoi(e) : 0; }
+    // one max chain, three waves per SIMD: 2 / 4 chains and 2 waves per SIMD measured within 2 % (same log)
     if (!d->q_prescaled) hipLaunchKernelGGL((attn_kernel<false, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
-    else if (var == 1) hipLaunchKernelGGL((attn_kernel<true, 2, 3>), dim3(grid), dim3(256), 0, stream, a);
-    else if (var == 2) hipLaunchKernelGGL((attn_kernel<true, 4, 2>), dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((attn_kernel<true, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));

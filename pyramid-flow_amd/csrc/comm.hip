@@ -1,0 +1,207 @@
+// Communicator of the C ABI (include/pyflow_hip.h, "multi-GPU"): RCCL over xGMI, one process per GPU.
+//
+// Replaces the collectives the reference issues through torch.distributed -- `dist.all_to_all` inside
+// trainer_misc/communicate.py:7-26 (sequence parallelism), the isend / irecv halo pass and the list all_gather of
+// video_vae/context_parallel_ops.py:41-114 (context parallelism), the per-step broadcast of
+// pyramid_dit_for_video_gen_pipeline.py:752-756 -- for hosts that do not carry torch.distributed.  The Python host of
+// this repository keeps torch.distributed (backend "nccl" = the same RCCL) as its default client and can be switched to
+// this communicator (pyflow_hip/comm_native.py).
+//
+// Every collective is enqueued on the communicator's OWN HIP stream, ordered after the work already queued on the
+// caller's compute stream (event), so that kernels launched next on the compute stream overlap with it; pf_comm_wait
+// makes a stream wait for everything the communicator has queued (event, no host sync).  No allocation, no host
+// synchronisation.  RCCL is resolved at run time (dlopen of the library the process already has: no link dependency,
+// one RCCL per process even next to torch).
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+#include "pyflow_hip.h"
+
+int pf_set_err(const char* m);
+
+namespace {
+
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void* rcclComm_t;
+enum { RCCL_INT8 = 0, RCCL_UINT8 = 1, RCCL_FLOAT32 = 7, RCCL_SUM = 0 };
+
+struct Api {
+    int (*GetUniqueId)(rcclUniqueId*);
+    int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int);
+    int (*CommDestroy)(rcclComm_t);
+    int (*GroupStart)();
+    int (*GroupEnd)();
+    int (*Send)(const void*, size_t, int, int, rcclComm_t, hipStream_t);
+    int (*Recv)(void*, size_t, int, int, rcclComm_t, hipStream_t);
+    int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
+    int (*Broadcast)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
+    const char* (*GetErrorString)(int);
+    bool ok = false;
+};
+Api g_api;
+
+bool load_api() {
+    if (g_api.ok) return true;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return false;
+#define PF_SYM(field, name)                                  \
+    *(void**)(&g_api.field) = dlsym(h, name);                \
+    if (!g_api.field) return false;
+    PF_SYM(GetUniqueId, "ncclGetUniqueId")
+    PF_SYM(CommInitRank, "ncclCommInitRank")
+    PF_SYM(CommDestroy, "ncclCommDestroy")
+    PF_SYM(GroupStart, "ncclGroupStart")
+    PF_SYM(GroupEnd, "ncclGroupEnd")
+    PF_SYM(Send, "ncclSend")
+    PF_SYM(Recv, "ncclRecv")
+    PF_SYM(AllReduce, "ncclAllReduce")
+    PF_SYM(Broadcast, "ncclBroadcast")
+    PF_SYM(GetErrorString, "ncclGetErrorString")
+#undef PF_SYM
+    g_api.ok = true;
+    return true;
+}
+
+int rccl_fail(const char* where, int rc) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: RCCL error %d (%s)", where, rc, g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
+    return pf_set_err(buf);
+}
+
+}  // namespace
+
+struct pf_comm {
+    rcclComm_t comm;
+    int rank, world;
+    hipStream_t stream;      // the communicator's own stream
+    hipEvent_t ev_in;        // compute stream -> comm stream ordering
+    hipEvent_t ev_out;       // comm stream -> waiting stream ordering
+};
+
+#define PF_RCCL(call, where)                      \
+    do {                                          \
+        const int rc_ = (call);                   \
+        if (rc_ != 0) return rccl_fail(where, rc_); \
+    } while (0)
+
+static int order_after(pf_comm* c, hipStream_t compute) {
+    if (hipEventRecord(c->ev_in, compute) != hipSuccess) return pf_set_err("pf_comm: hipEventRecord failed");
+    if (hipStreamWaitEvent(c->stream, c->ev_in, 0) != hipSuccess) return pf_set_err("pf_comm: hipStreamWaitEvent failed");
+    return 0;
+}
+
+extern "C" int pf_comm_unique_id(void* out128) {
+    if (!out128) return pf_set_err("pf_comm_unique_id: null buffer");
+    if (!load_api()) return pf_set_err("pf_comm: librccl.so not found");
+    rcclUniqueId id;
+    PF_RCCL(g_api.GetUniqueId(&id), "pf_comm_unique_id");
+    memcpy(out128, id.internal, 128);
+    return 0;
+}
+
+extern "C" int pf_comm_init(pf_comm** out, int rank, int world, const void* unique_id_128) {
+    if (!out || !unique_id_128 || world < 1 || rank < 0 || rank >= world) return pf_set_err("pf_comm_init: bad arguments");
+    if (!load_api()) return pf_set_err("pf_comm: librccl.so not found");
+    pf_comm* c = new pf_comm();
+    c->rank = rank;
+    c->world = world;
+    rcclUniqueId id;
+    memcpy(id.internal, unique_id_128, 128);
+    const int rc = g_api.CommInitRank(&c->comm, world, id, rank);
+    if (rc != 0) { delete c; return rccl_fail("pf_comm_init", rc); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return pf_set_err("pf_comm_init: stream / event creation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int pf_comm_destroy(pf_comm* c) {
+    if (!c) return 0;
+    hipStreamSynchronize(c->stream);
+    g_api.CommDestroy(c->comm);
+    hipEventDestroy(c->ev_in);
+    hipEventDestroy(c->ev_out);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int pf_comm_rank(const pf_comm* c) { return c ? c->rank : -1; }
+extern "C" int pf_comm_world(const pf_comm* c) { return c ? c->world : -1; }
+
+// all-to-all with per-peer byte counts / offsets (counts of 0 allowed): one grouped ncclSend / ncclRecv per peer
+extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* send_bytes, const long long* send_offs,
+                               void* recv, const long long* recv_bytes, const long long* recv_offs, hipStream_t compute) {
+    if (!c || !send_bytes || !send_offs || !recv_bytes || !recv_offs) return pf_set_err("pf_all_to_all_v: null argument");
+    if (order_after(c, compute)) return -1;
+    PF_RCCL(g_api.GroupStart(), "pf_all_to_all_v");
+    for (int p = 0; p < c->world; ++p) {
+        if (send_bytes[p] > 0)
+            PF_RCCL(g_api.Send((const char*)send + send_offs[p], (size_t)send_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
+        if (recv_bytes[p] > 0)
+            PF_RCCL(g_api.Recv((char*)recv + recv_offs[p], (size_t)recv_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
+    }
+    PF_RCCL(g_api.GroupEnd(), "pf_all_to_all_v");
+    return 0;
+}
+
+// halo pass of the temporal context parallelism: `bytes` go to rank + 1, rank - 1's arrive in `recv`; no wrap-around
+extern "C" int pf_halo_send_recv(pf_comm* c, const void* send, void* recv, long long bytes, hipStream_t compute) {
+    if (!c || bytes < 0) return pf_set_err("pf_halo_send_recv: bad arguments");
+    if (order_after(c, compute)) return -1;
+    PF_RCCL(g_api.GroupStart(), "pf_halo_send_recv");
+    if (c->rank + 1 < c->world && bytes > 0)
+        PF_RCCL(g_api.Send(send, (size_t)bytes, RCCL_UINT8, c->rank + 1, c->comm, c->stream), "pf_halo_send_recv");
+    if (c->rank > 0 && bytes > 0)
+        PF_RCCL(g_api.Recv(recv, (size_t)bytes, RCCL_UINT8, c->rank - 1, c->comm, c->stream), "pf_halo_send_recv");
+    PF_RCCL(g_api.GroupEnd(), "pf_halo_send_recv");
+    return 0;
+}
+
+// every rank receives rank p's `bytes[p]` bytes at recv + offs[p] (uneven parts allowed); `send` = this rank's part
+extern "C" int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const long long* bytes, const long long* offs,
+                               hipStream_t compute) {
+    if (!c || !bytes || !offs) return pf_set_err("pf_all_gather_v: null argument");
+    if (order_after(c, compute)) return -1;
+    PF_RCCL(g_api.GroupStart(), "pf_all_gather_v");
+    for (int p = 0; p < c->world; ++p) {
+        if (bytes[c->rank] > 0)
+            PF_RCCL(g_api.Send(send, (size_t)bytes[c->rank], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
+        if (bytes[p] > 0)
+            PF_RCCL(g_api.Recv((char*)recv + offs[p], (size_t)bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
+    }
+    PF_RCCL(g_api.GroupEnd(), "pf_all_gather_v");
+    return 0;
+}
+
+extern "C" int pf_all_reduce_sum_f32(pf_comm* c, float* buf, long long count, hipStream_t compute) {
+    if (!c || !buf || count < 0) return pf_set_err("pf_all_reduce_sum_f32: bad arguments");
+    if (order_after(c, compute)) return -1;
+    PF_RCCL(g_api.AllReduce(buf, buf, (size_t)count, RCCL_FLOAT32, RCCL_SUM, c->comm, c->stream), "pf_all_reduce_sum_f32");
+    return 0;
+}
+
+extern "C" int pf_broadcast_bytes(pf_comm* c, void* buf, long long bytes, int root, hipStream_t compute) {
+    if (!c || !buf || bytes < 0 || root < 0 || root >= c->world) return pf_set_err("pf_broadcast_bytes: bad arguments");
+    if (order_after(c, compute)) return -1;
+    PF_RCCL(g_api.Broadcast(buf, buf, (size_t)bytes, RCCL_UINT8, root, c->comm, c->stream), "pf_broadcast_bytes");
+    return 0;
+}
+
+// `stream` waits (on the device) for everything queued on the communicator so far
+extern "C" int pf_comm_wait(pf_comm* c, hipStream_t stream) {
+    if (!c) return pf_set_err("pf_comm_wait: null communicator");
+    if (hipEventRecord(c->ev_out, c->stream) != hipSuccess) return pf_set_err("pf_comm_wait: hipEventRecord failed");
+    if (hipStreamWaitEvent(stream, c->ev_out, 0) != hipSuccess) return pf_set_err("pf_comm_wait: hipStreamWaitEvent failed");
+    return 0;
+}

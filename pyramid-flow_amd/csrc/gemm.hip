@@ -13,7 +13,6 @@
 // of tile k+1 are issued right after the barrier that publishes tile k and fly under its MFMAs.
 // Epilogue: accumulators are staged through LDS as fp32, then every thread streams whole
 // 16-byte bf16 pieces (bias / GELU-tanh / gate*x+residual applied in fp32) -> coalesced stores.
-#include <stdlib.h>
 #include "common.h"
 #include "pyflow_hip.h"
 #include "gemm_args.h"
@@ -205,20 +204,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
 int pf_set_err(const char* m);
 #define set_err pf_set_err
 int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force);
-int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, int variant, hipStream_t stream);
+int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, hipStream_t stream);
 int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream);      // gemm8p.hip: persistent 256 x 256 tiles
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 
-// PF_GEMM256 = 0 (auto, default) | 128 | 192 | 256 (force that tile width when it divides N) | -1 (never)
-static int g_gemm256_force = -2;
-static int g_gemm256_variant = 1;      // 0: barrier per slot, 1: one barrier per K-tile
-static int gemm256_force() {
-    if (g_gemm256_force == -2) {
-        const char* e = getenv("PF_GEMM256");
-        g_gemm256_force = e ? atoi(e) : 0;
-    }
-    return g_gemm256_force;
-}
+// tile-width policy of the 256-row ping-pong kernels: 0 (auto, default) | 128 | 192 | 256 (that width when it divides N) | -1 (never)
+static int g_gemm256_force = 0;
+static int gemm256_force() { return g_gemm256_force; }
 // gemm8p (persistent 256 x 256 tiles): 1 = whenever legal (policy 8), 0 = automatic, -1 = never (policy -8)
 static int g_gemm8p_mode = 0;
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
@@ -226,7 +218,8 @@ static bool use_gemm8p(int M, int batch, int N, int K) {
     if (g_gemm8p_mode < 0 || N % 8 || K % 64) return false;
     if (g_gemm8p_mode > 0) return true;
     if (!g_gemm8p_auto || gemm256_force() != 0) return false;          // an explicit tile-width policy addresses the older kernels
-    // automatic: problems of at least one full round of 256 x 256 tiles whose N tail wastes < 7 % of the columns
+    // automatic: problems of at least 3/4 of a round of 256 x 256 tiles whose N tail wastes < 7 % of the columns
+    // (a sequence-parallel rank at P = 8 runs the 7d-wide projections with 16 x 53 tiles and the 4d-wide with 16 x 30)
     const long long tiles = (long long)((M + 255) / 256) * batch * ((N + 255) / 256);
     const int n256 = (N + 255) / 256 * 256;
     return tiles >= 192 && (n256 - N) * 100 < 7 * N;
@@ -239,17 +232,10 @@ extern "C" int pf_gemm_set_policy(int force) {
     g_gemm8p_mode = 0;
     return 0;
 }
-extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>, -BN = gemm256w4_kernel<BN>
+extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>
     if (use_gemm8p(M, batch, N, K)) return 8;
-    const int bn = pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
-    const bool w4 = (bn == 192 || bn == 256) && g_gemm256_variant == 3;
-    return w4 ? -bn : bn;
+    return pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
 }
-extern "C" int pf_gemm_set_variant(int v) {     // tuning hook, not part of the documented ABI
-    g_gemm256_variant = v;
-    return 0;
-}
-
 extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
     if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
@@ -267,11 +253,7 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
     a.out_scale = 1.f; a.n_valid = d->N;
     if (a.gelu_from % 8) return set_err("pf_gemm_bf16: gelu_from must be a multiple of 8");
-    {
-        static int gmv = -1;
-        if (gmv < 0) { const char* e = getenv("PF_GEMM_GROUPM"); gmv = e ? atoi(e) : 0; }
-        a.group_m = gmv;
-    }
+    a.group_m = 0;
     if (use_gemm8p(d->M, d->batch, d->N, d->K) && pf_gemm8p_supports(a, false)) {
         pf_gemm8p_launch(a, false, stream);
         hipError_t e2 = hipGetLastError();
@@ -279,7 +261,7 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
         return 0;
     }
     if (const int bn = bn256) {
-        pf_gemm256_launch(a, bn, false, g_gemm256_variant, stream);
+        pf_gemm256_launch(a, bn, false, stream);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
         return 0;
@@ -317,7 +299,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
         return 0;
     }
     if (const int bn = pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force())) {
-        pf_gemm256_launch(a, bn, true, g_gemm256_variant, stream);
+        pf_gemm256_launch(a, bn, true, stream);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
         return 0;

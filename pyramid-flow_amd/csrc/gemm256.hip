@@ -169,143 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
-    if constexpr (V == 2) {
-        // ---- variant 2: register-prefetch pipeline, all 8 waves in step.  Fragments of phase p+1 are requested from
-        // LDS before the MFMAs of phase p issue (two fragment sets), B(t+2) / A(t+2) are requested a full K-tile
-        // ahead, ONE barrier per K-tile sits between two MFMA phases (every wave has its next MFMAs' operands in
-        // registers when it is released).
-        constexpr int KS = (BN == 256) ? 1 : 2;      // 16-wide k-steps per phase
-        constexpr int PH = 4 / KS;                   // phases per K-tile
-        bf16x8_t fa[2][2][KS], fb[2][NT][KS];
-        auto loadF = [&](int set, int stg, int bufi, int ph) {
-            const char* sa = sA + stg * A_STAGE + a_row_off;
-            const char* sb = sB + bufi * C_::B_STAGE + b_row_off;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const int ch = ((2 * (KS * ph + kk) + fhi) ^ fswz) << 4;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) fa[set][i][kk] = *(const bf16x8_t*)(sa + i * 32 * 128 + ch);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) fb[set][j][kk] = *(const bf16x8_t*)(sb + j * 32 * 128 + ch);
-            }
-        };
-        // MFMAs of fragment set `set`; `between` (next phase's LDS reads / DMA issue / tile hand-over) is placed after
-        // the FIRST MFMA: the compiler's lgkmcnt wait for this set then precedes the new reads (it cannot count
-        // across them), and the reads land under the remaining MFMAs.
-        auto phase = [&](int set, auto&& between) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][0][0], fb[set][0][0], acc[0][0], 0, 0, 0);
-            PF_SCHED_FENCE();
-            between();
-            PF_SCHED_FENCE();
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        if (kk | i | j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i][kk], fb[set][j][kk], acc[i][j], 0, 0, 0);
-        };
-        issueA(0, 0);
-        issueB(0, 0);
-        if (nk > 1) {
-            issueA(1, 1);
-            issueB(1, 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        PF_BARRIER();
-        loadF(0, 0, 0, 0);
-        int stage = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-            const int stage_n = stage == 2 ? 0 : stage + 1;
-#pragma unroll
-            for (int ph = 0; ph < PH; ++ph) {
-                const int cur = ph & 1, nxt = cur ^ 1;
-                phase(cur, [&]() {
-                    if (ph == PH - 1) {
-                        if (more1) {
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            PF_BARRIER();
-                            if (more2) issueB(kt + 2, buf);
-                            loadF(nxt, stage_n, buf ^ 1, 0);
-                        }
-                    } else {
-                        loadF(nxt, stage, buf, ph + 1);
-                    }
-                    if (ph == 0 && more2) issueA(kt + 2, stage == 0 ? 2 : stage - 1);
-                });
-            }
-            stage = stage_n;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PF_BARRIER();          // every wave is done with the operand tiles before the epilogue strips overwrite them
-    } else if constexpr (V == 11) {
-    // ---- variant 11 (diagnostic): variant 1's loop with s_memtime stamps around the four slots and the two barrier
-    // waits; workgroup 0 writes per-wave cycle sums to p.gate (float[8 waves][8]: L0, M0, L1, wait+barrier (group 1),
-    // M1, wait+barrier (group 0), K-tiles).  Stamps cost time themselves: read the numbers as proportions.
-    issueA(0, 0);
-    issueB(0, 0);
-    if (nk > 1) {
-        issueA(1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    PF_BARRIER();
-    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
-    auto now = [&]() -> unsigned long long {
-        PF_SCHED_FENCE();
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PF_SCHED_FENCE();
-        return t;
-    };
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more2 = kt + 2 < nk;
-        const unsigned long long t0 = now();
-        load_frags(stage, buf, 0);
-        if (kt + 1 < nk) issueB(kt + 1, buf ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t1 = now();
-        mfma_slot();
-        const unsigned long long t2 = now();
-        load_frags(stage, buf, 1);
-        if (more2) issueA(kt + 2, stage == 0 ? 2 : stage - 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t3 = now();
-        if (g == 1) {
-            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PF_BARRIER();
-        }
-        const unsigned long long t4 = now();
-        mfma_slot();
-        const unsigned long long t5 = now();
-        if (g == 0) {
-            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PF_BARRIER();
-        }
-        const unsigned long long t6 = now();
-        acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2;
-        acc_t[3] += t4 - t3; acc_t[4] += t5 - t4; acc_t[5] += t6 - t5;
-        stage = stage == 2 ? 0 : stage + 1;
-    }
-    if (blockIdx.x == 0 && lane == 0 && p.gate) {
-        float* o = const_cast<float*>(p.gate) + wid * 8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = (float)acc_t[k];
-        o[6] = (float)nk;
-    }
-    } else {
+    {
     // ---- prologue: A(0), B(0), A(1) (variant 4 also B(1): B runs two K-tiles ahead like A)
     constexpr bool B3 = (V == 4);
     issueA(0, 0);
@@ -322,7 +186,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PF_BARRIER();
-    if (V == 0 && g == 1) PF_BARRIER();          // group 1 runs one slot behind group 0
 
     int stage = 0;                     // A stage of tile kt = kt % 3
     for (int kt = 0; kt < nk; ++kt) {
@@ -336,10 +199,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
             issueB(kt + 1, buf ^ 1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (V == 0) PF_BARRIER(); else PF_SCHED_FENCE();
+        PF_SCHED_FENCE();
         // ---- slot M0
         mfma_slot();
-        if (V == 0) PF_BARRIER(); else PF_SCHED_FENCE();
+        PF_SCHED_FENCE();
         // ---- slot L1: fragments of K-half 1, prefetch A(kt+2)
         load_frags(stage, buf, 1);
         if (more2) issueA(kt + 2, stage == 0 ? 2 : stage - 1);
@@ -347,8 +210,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         if (g == 1) {                  // group 1: this barrier is the one before group 0 reads tile kt+1
             if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B3 ? 4 + NT : 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PF_BARRIER();
-        } else if (V == 0) {
             PF_BARRIER();
         } else {
             PF_SCHED_FENCE();
@@ -358,8 +219,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
         if (g == 0) {
             if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B3 ? 4 + NT : 4) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PF_BARRIER();
-        } else if (V == 0 && kt + 1 < nk) {
             PF_BARRIER();
         } else {
             PF_SCHED_FENCE();
@@ -484,29 +343,21 @@ int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force) {
     else if (N % 128 == 0 && M_total >= 65536) bn = 128;
     if (!bn) return 0;
     // small problems: the 128x128 tiles (2 blocks / CU) fill the 256 CUs better
-    const long long tiles = (long long)((M + BM - 1) / BM) * batch * ((N + bn - 1) / bn);
-    return tiles >= 192 ? bn : 0;
+    auto tiles_of = [&](int w) { return (long long)((M + BM - 1) / BM) * batch * ((N + w - 1) / w); };
+    if (tiles_of(bn) >= 192) return bn;
+    // mid-size problems (a sequence-parallel rank at P = 8: M ~ 2 x 1 936 rows, N = 1 920): too few 256 x 192 tiles
+    // for one round of the chip, but 256 x 128 tiles fill it (16 x 15 = 240) and still run the ping-pong kernel
+    // instead of the 128 x 128 kernel that this shape used to fall back to (0.09 of peak in the round-1 profile)
+    if (bn != 128 && N % 128 == 0 && tiles_of(128) >= 192) return 128;
+    return 0;
 }
 
-int pf_gemm256w4_launch(const Args& a, int bn, bool conv, hipStream_t stream, int dbg = 0);
-int pf_gemm256p_launch(const Args& a, int bn, bool conv, hipStream_t stream);
-
-int pf_gemm256_launch(const Args& a, int bn, bool conv, int variant, hipStream_t stream) {
-    if (variant == 11 && !conv && bn != 128) return bn == 256 ? launch<256, false, 11>(a, stream) : launch<192, false, 11>(a, stream);
-    if (variant == 10) return pf_gemm256p_launch(a, bn, conv, stream);            // persistent tile walk (gemm256p.hip)
-    if (variant == 3 && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream);
-    if ((variant == 5 || variant == 6) && (bn == 256 || bn == 192)) return pf_gemm256w4_launch(a, bn, conv, stream, variant - 4);
-    // BN = 128 leaves room for a third B stage (144 KiB): B then runs two K-tiles ahead like A (+2-5 %); this is what the
-    // default variant 1 runs for BN = 128, variant 0 keeps the two-stage ping-pong form
-    if ((variant == 1 || variant == 4) && bn == 128)
-        return conv ? launch<128, true, 4>(a, stream) : launch<128, false, 4>(a, stream);
-#define PF_L(BN_) (conv ? (variant == 2 ? launch<BN_, true, 2>(a, stream) : launch<BN_, true, 1>(a, stream)) \
-                        : (variant == 2 ? launch<BN_, false, 2>(a, stream) : (variant ? launch<BN_, false, 1>(a, stream) : launch<BN_, false, 0>(a, stream))))
+int pf_gemm256_launch(const Args& a, int bn, bool conv, hipStream_t stream) {
+    // BN = 128 leaves room for a third B stage (144 KiB): B then runs two K-tiles ahead like A (+2-5 %, V = 4)
     switch (bn) {
-        case 128: return PF_L(128);
-        case 192: return PF_L(192);
-        case 256: return PF_L(256);
+        case 128: return conv ? launch<128, true, 4>(a, stream) : launch<128, false, 4>(a, stream);
+        case 192: return conv ? launch<192, true, 1>(a, stream) : launch<192, false, 1>(a, stream);
+        case 256: return conv ? launch<256, true, 1>(a, stream) : launch<256, false, 1>(a, stream);
     }
-#undef PF_L
     return -1;
 }

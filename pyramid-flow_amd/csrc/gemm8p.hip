@@ -528,8 +528,6 @@ int launch(const Args& a, hipStream_t stream) {
 
 }  // namespace
 
-static int g_diag = 0;
-extern "C" int pf_gemm8p_diag(int d) { g_diag = d; return 0; }     // measurement hook (temporary)
 
 // Epilogue flavours that exist as instantiations: bias (+ out_scale for conv) always; ONE of {residual (+gate),
 // fp32 output, GELU-tanh from a column}.  Anything else (CLIP activations, combinations) is served by the older kernels.
@@ -543,7 +541,7 @@ bool pf_gemm8p_supports(const Args& a, bool conv) {
 
 int pf_gemm8p_launch(const Args& a_in, bool conv, hipStream_t stream) {
     Args a = a_in;
-    a.diag = g_diag;
+    a.diag = 0;
     const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
     if (conv) return res ? launch<true, 1>(a, stream) : launch<true, 0>(a, stream);
     if (res) return launch<false, 1>(a, stream);

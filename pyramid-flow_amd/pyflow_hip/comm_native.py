@@ -1,0 +1,162 @@
+"""`NativeComm`: the SPComm interface (pyflow_hip/sp.py) on the C-ABI communicator (pf_comm_*, csrc/comm.hip) instead of
+torch.distributed -- RCCL driven directly, collectives on the communicator's own HIP stream, ordering by events.
+
+The default client of the multi-GPU paths remains torch.distributed (backend "nccl" is the same RCCL); this class is the
+proof that a host WITHOUT torch.distributed can drive them through the C ABI alone, and an opt-in for the Python host
+(`init_sequence_parallel_group(args, native=True)`).  Bootstrap: rank 0 draws the 128-byte unique id
+(pf_comm_unique_id) and publishes it -- here through a file or an existing torch.distributed store; any byte channel
+works.
+"""
+import ctypes as C
+import os
+import time
+
+import torch
+
+from . import lib as L
+from .lib import check
+from .sp import starts_of
+
+
+def exchange_unique_id(rank, world, path=None):
+    """128-byte RCCL unique id from rank 0 to everyone: through torch.distributed when a process group exists,
+    otherwise through the file `path` (rank 0 writes it atomically, the others poll)."""
+    lib = L.load()
+    buf = (C.c_char * 128)()
+    if world == 1:
+        check(lib.pf_comm_unique_id(buf))
+        return bytes(buf)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        t = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            check(lib.pf_comm_unique_id(buf))
+            t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, 0)
+        return bytes(t.cpu().numpy().tobytes())
+    assert path is not None, "no torch.distributed group: pass a file path every rank can read"
+    if rank == 0:
+        check(lib.pf_comm_unique_id(buf))
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(bytes(buf))
+        os.replace(tmp, path)
+        return bytes(buf)
+    deadline = time.time() + 300
+    while not os.path.exists(path):
+        if time.time() > deadline:
+            raise TimeoutError(f"unique id file {path} never appeared")
+        time.sleep(0.05)
+    with open(path, "rb") as f:
+        return f.read()
+
+
+class NativeComm:
+    native = True
+    backend = "pf_comm"
+
+    def __init__(self, rank, world, unique_id):
+        lib = L.load()
+        self._lib = lib
+        self.rank, self.world = rank, world
+        self.group = None
+        h = C.c_void_p()
+        check(lib.pf_comm_init(C.byref(h), C.c_int(rank), C.c_int(world), C.c_char_p(unique_id)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.pf_comm_destroy(self._h)
+            self._h = None
+
+    @staticmethod
+    def _cur():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    class _Handle:
+        def __init__(self, comm):
+            self.comm = comm
+
+        def wait(self):
+            """the CURRENT stream waits for the exchange on the device (no host sync), like a c10d work handle"""
+            check(self.comm._lib.pf_comm_wait(self.comm._h, NativeComm._cur()))
+
+    def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
+        esz = send.element_size()
+        P = self.world
+        arr = C.c_longlong * P
+        so, ro = starts_of(send_splits), starts_of(recv_splits)
+        check(self._lib.pf_all_to_all_v(self._h, C.c_void_p(send.data_ptr()), arr(*[s * esz for s in send_splits]),
+                                        arr(*[o * esz for o in so]), C.c_void_p(recv.data_ptr()),
+                                        arr(*[r * esz for r in recv_splits]), arr(*[o * esz for o in ro]), self._cur()))
+        h = self._Handle(self)
+        if async_op:
+            return h
+        h.wait()
+        return None
+
+    def all_reduce(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        check(self._lib.pf_all_reduce_sum_f32(self._h, C.c_void_p(t.data_ptr()), C.c_longlong(t.numel()), self._cur()))
+        self._Handle(self).wait()
+        return t
+
+    def broadcast(self, t, src=0):
+        assert t.is_contiguous()
+        check(self._lib.pf_broadcast_bytes(self._h, C.c_void_p(t.data_ptr()), C.c_longlong(t.numel() * t.element_size()),
+                                           C.c_int(src), self._cur()))
+        self._Handle(self).wait()
+        return t
+
+    def shift(self, send_t, recv_t):
+        s_ = send_t.contiguous()
+        assert recv_t.is_contiguous()
+        check(self._lib.pf_halo_send_recv(self._h, C.c_void_p(s_.data_ptr()), C.c_void_p(recv_t.data_ptr()),
+                                          C.c_longlong(s_.numel() * s_.element_size()), self._cur()))
+        self._Handle(self).wait()
+
+    def all_gather_v(self, send, recv, counts):
+        """recv <- concatenation of every rank's `send` (element counts per rank in `counts`)"""
+        esz = send.element_size()
+        arr = C.c_longlong * self.world
+        check(self._lib.pf_all_gather_v(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                        arr(*[c * esz for c in counts]), arr(*[o * esz for o in starts_of(counts)]),
+                                        self._cur()))
+        self._Handle(self).wait()
+        return recv
+
+    def barrier(self):
+        t = torch.zeros(1, dtype=torch.float32, device="cuda")
+        self.all_reduce(t)
+        torch.cuda.current_stream().synchronize()
+
+    # point-to-point of the tile-parallel decode: expressed through the v-collectives (a send is an all-to-all with one
+    # non-zero count); the pair must call send / recv in matching order, like c10d's send / recv
+    def send(self, t, dst):
+        s_ = t.contiguous()
+        n = s_.numel()
+        zeros = [0] * self.world
+        ss = list(zeros)
+        ss[dst] = n
+        self.all_to_all_pair(s_, None, ss, zeros, peer=dst)
+
+    def recv(self, t, src):
+        zeros = [0] * self.world
+        rs = list(zeros)
+        rs[src] = t.numel()
+        self.all_to_all_pair(None, t, zeros, rs, peer=src)
+        return t
+
+    def all_to_all_pair(self, send, recv, send_splits, recv_splits, peer):
+        """two-rank exchange (only `peer` and this rank take part: grouped ncclSend / ncclRecv involve just the pair)"""
+        ref = send if send is not None else recv
+        esz = ref.element_size()
+        arr = C.c_longlong * self.world
+        zero = arr(*([0] * self.world))
+        check(self._lib.pf_all_to_all_v(self._h, C.c_void_p(send.data_ptr() if send is not None else 0),
+                                        arr(*[s * esz for s in send_splits]), zero,
+                                        C.c_void_p(recv.data_ptr() if recv is not None else 0),
+                                        arr(*[r * esz for r in recv_splits]), zero, self._cur()))
+        self._Handle(self).wait()

@@ -334,12 +334,23 @@ class PyramidDiTForVideoGeneration:
         # with a sequence-parallel group the decode is tile-parallel over the same ranks (the reference leaves every
         # rank but 0 idle here, pipeline.py:1223-1224); frames are assembled on rank 0, other ranks return None
         comm = self.sp if (self.sp is not None and self.vae.use_tiling) else None
+        # a context-parallel group (utils.initialize_context_parallel, the reference's switch: every CausalConv3d diverts
+        # to the halo-exchange path whenever that group exists, modeling_causal_conv.py:119-120) selects the temporal
+        # context-parallel decode: un-tiled, frame ranges over the ranks, one halo exchange per causal conv
+        from . import cp as cp_mod
+        if cp_mod.is_context_parallel_initialized() and cp_mod.get_context_parallel_world_size() > 1:
+            return self._finish_frames(self.vae.decode_context_parallel(z, cp_mod.get_context_parallel_comm(), affine=aff),
+                                       output_type)
         if self.sp is not None and comm is None and self.sp.rank != 0:
             return None
         if save_memory:
             u8 = self.vae.decode_to_uint8(z, window_size=1, tile_sample_min_size=256, affine=aff, comm=comm)
         else:
             u8 = self.vae.decode_to_uint8(z, window_size=2, tile_sample_min_size=512, affine=aff, comm=comm)
+        return self._finish_frames(u8, output_type)
+
+    @staticmethod
+    def _finish_frames(u8, output_type):
         if u8 is None or output_type == "uint8":
             return u8
         arr = u8.cpu().numpy()

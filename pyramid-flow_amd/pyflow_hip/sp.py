@@ -234,11 +234,19 @@ _SP = None
 _SP_PROC_NUM = None
 
 
-def init_sequence_parallel_group(args=None, sp_group_size=None):
+def init_sequence_parallel_group(args=None, sp_group_size=None, native=False):
     """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world) over the
-    first `args.sp_proc_num` processes (-1 / absent = all).  A process outside every group stays un-initialised."""
+    first `args.sp_proc_num` processes (-1 / absent = all).  A process outside every group stays un-initialised.
+    native=True (whole-world group only): the collectives go through the C-ABI communicator (pf_comm_*, RCCL driven
+    directly on its own HIP stream) instead of torch.distributed; torch.distributed is used once, to ship the id."""
     global _SP, _SP_PROC_NUM
     world = dist.get_world_size()
+    if native:
+        from .comm_native import NativeComm, exchange_unique_id
+        rank = dist.get_rank()
+        _SP_PROC_NUM = world
+        _SP = NativeComm(rank, world, exchange_unique_id(rank, world))
+        return _SP
     size = sp_group_size or getattr(args, "sp_group_size", None) or world
     proc = getattr(args, "sp_proc_num", -1) if args is not None else -1
     proc = world if proc in (-1, None) else proc

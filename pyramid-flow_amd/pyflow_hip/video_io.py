@@ -66,6 +66,19 @@ class FrameRing:
         return self.slots[i][:n].numpy()
 
 
+def frames_to_host(frames, pinned=None):
+    """uint8 frames [T,H,W,3] on the device -> the same bytes in PINNED host memory (one asynchronous copy on the current
+    stream + a stream sync).  `pinned`: a reusable pinned uint8 tensor of at least that many bytes (allocated when None).
+    This is the end point of the sampling metric ("uint8 frames in host memory")."""
+    n = frames.numel()
+    if pinned is None or pinned.numel() < n:
+        pinned = torch.empty(n, dtype=torch.uint8).pin_memory()
+    host = pinned[:n].view(frames.shape)
+    host.copy_(frames, non_blocking=True)
+    torch.cuda.current_stream(frames.device).synchronize()
+    return host
+
+
 def _yuv_call(rgb, y_ptr, u_ptr, v_ptr, y_fs, c_fs):
     T, H, W, _ = rgb.shape
     check(L.load().pf_rgb_to_yuv420(C.c_void_p(rgb.data_ptr()), C.c_void_p(y_ptr), C.c_void_p(u_ptr), C.c_void_p(v_ptr),
@@ -102,8 +115,11 @@ def _write_y4m(frames, path, fps, block):
     if (H | W) & 1:
         raise ValueError("y4m 4:2:0 needs even frame dimensions")
     if not frames.is_cuda:
-        raise RuntimeError("the .y4m writer converts colours on the device: pass the frames as a CUDA uint8 tensor "
-                           "(output_type='uint8')")
+        # PIL / numpy / host frames (what generate() returns by default, output_type="pil"): the colour conversion runs
+        # on the device, so they are uploaded first (one H2D of the uint8 frames)
+        if not torch.cuda.is_available():
+            raise RuntimeError("the .y4m writer converts colours on the MI355X: no device is visible")
+        frames = frames.cuda()
     per = H * W * 3 // 2
     ring = FrameRing(per * block, slots=3, device=frames.device)
     pending = []

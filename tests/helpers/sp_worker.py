@@ -10,6 +10,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -52,9 +53,21 @@ def main():
         ref_eng.encode_context(enc)
         ref = ref_eng.forward_tokens(plan, clips, t, pooled).clone()
         err = rel_l2(v.cpu(), ref.cpu())
-        ok = err < 2e-3
+        # ... and against the CPU oracle (the reference's arithmetic), not only against the single-rank HIP engine
+        if variant == "mmdit":
+            from oracle.mmdit_oracle import mmdit_forward as oracle_forward
+        else:
+            from oracle.flux_oracle import flux_forward as oracle_forward
+        o_ref = oracle_forward(sd, cfg, [c.cpu() for c in clips], enc, mask, pooled, torch.tensor(t))
+        tcur, hcur, wcur = plan.cur
+        Cc = eng.w.out_cols // 4
+        x = v.cpu()[:, :, :eng.w.out_cols].reshape(2, tcur, hcur // 2, wcur // 2, 2, 2, Cc)
+        x = x.permute(0, 1, 2, 4, 3, 5, 6).reshape(2, tcur, hcur, wcur, Cc).permute(0, 4, 1, 2, 3)
+        err_oracle = rel_l2(x, o_ref)
+        ok = err < 2e-3 and err_oracle < 2e-2
         with open(out_path, "w") as f:
-            f.write(f"{err:.3e} {int(ok)} world={world} heads={heads} lay_rows={eng.layout(plan).rows} lay_heads={eng.layout(plan).heads}\n")
+            f.write(f"vs single-rank HIP {err:.3e}, vs oracle {err_oracle:.3e} {int(ok)} world={world} heads={heads} "
+                    f"lay_rows={eng.layout(plan).rows} lay_heads={eng.layout(plan).heads}\n")
     # all ranks must hold the same replicated result
     gathered = [torch.empty_like(v.cpu()) for _ in range(world)]
     dist.all_gather(gathered, v.cpu())

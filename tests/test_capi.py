@@ -24,6 +24,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.load().pf_version() >= 1
 
 
+def test_library_exports_nothing_undeclared():
+    """no tuning hooks or experiment entry points in the shipping library: every exported pf_* symbol is in the header"""
+    import subprocess
+    from pyflow_hip import lib
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("pf_")})
+    extra = [n for n in exported if n not in _declared()]
+    assert not extra, f"exported but not declared in include/pyflow_hip.h: {extra}"
+
+
+def test_no_environment_hooks_in_the_kernels():
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "pyramid-flow_amd", "csrc", "*.hip")):
+        assert "getenv" not in open(f).read(), f
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from pyflow_hip import lib
     monkeypatch.setattr(lib, "_lib", None)

@@ -20,6 +20,18 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 REF = "/root/reference"
+_DROPIN = ("pyramid_dit", "trainer_misc", "utils", "video_vae", "diffusion_schedulers")
+
+
+@pytest.fixture(autouse=True)
+def _isolate_dropin_modules():
+    """the drop-in packages carry the reference's top-level names: forget them afterwards so that the tests which
+    import the real reference from /root/reference (tests/test_oracle_vs_reference.py) see their own modules"""
+    import sys
+    before = {k for k in sys.modules if k.split(".")[0] in _DROPIN}
+    yield
+    for k in [k for k in sys.modules if k.split(".")[0] in _DROPIN and k not in before]:
+        del sys.modules[k]
 
 
 def _calls_on(tree, root):

@@ -15,13 +15,11 @@ def _mk(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 10])
-def policy(request):
+@pytest.fixture
+def policy():
     from pyflow_hip import ops
-    ops.L.load().pf_gemm_set_variant(request.param)     # 0: barrier per slot, 1: one barrier per K-tile, 2: register-prefetch pipeline, 3: four waves with 128-row wave tiles, 10: persistent tile walk
     yield ops.gemm_set_policy
     ops.gemm_set_policy(0)
-    ops.L.load().pf_gemm_set_variant(1)
 
 
 @pytest.mark.parametrize("bn,M,N,K", [

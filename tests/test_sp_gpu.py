@@ -74,9 +74,11 @@ def _launch(world, script, args, tmp_path):
     print(out.read_text())
 
 
-@pytest.mark.parametrize("world,heads,variant", [(2, 4, "flux"), (3, 4, "flux"), (4, 6, "flux"), (3, 4, "mmdit")])
+@pytest.mark.parametrize("world,heads,variant", [(2, 4, "flux"), (3, 4, "flux"), (4, 6, "flux"), (3, 4, "mmdit"),
+                                                 (8, 10, "flux")])
 def test_sp_multi_process_exchange(tmp_path, world, heads, variant):
-    """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 6 over 4); miniFLUX and the SD3-style MMDiT."""
+    """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 6 over 4, 10 over 8 = the 2|2|1|1|1|1|1|1 analogue
+    of the benchmark's 30 heads over 8 ranks); miniFLUX and the SD3-style MMDiT; rank 0 also checks the CPU oracle."""
     _launch(world, "sp_worker.py", [heads, variant], tmp_path)
 
 
@@ -95,6 +97,14 @@ def test_vae_context_parallel(tmp_path, world, T):
 def test_rccl_api_on_one_rank():
     """the torch.distributed calls of the N > 1 path against the real RCCL library (backend nccl, world size 1)"""
     p = subprocess.run([sys.executable, os.path.join(HERE, "helpers", "nccl_world1.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    print(p.stdout.decode()[-200:])
+
+
+def test_native_communicator_on_one_rank():
+    """pf_comm_* (the C-ABI communicator: RCCL resolved at run time, own stream, event ordering) against the real library"""
+    p = subprocess.run([sys.executable, os.path.join(HERE, "helpers", "native_comm_world1.py")], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=300)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     print(p.stdout.decode()[-200:])
