@@ -176,6 +176,10 @@ int pf_gn_apply(const void* x, void* y, const double* stats, const float* gamma,
 /* row softmax of S (bf16, in place) * scale over the first n_valid columns, zero beyond (mid-block attention,
  * diffusers Attention with upcast_softmax; modeling_block.py:413-427) */
 int pf_softmax_rows(void* S, int ld, int n_valid, int n_cols, int rows, float scale, pf_stream_t stream);
+/* every conv-cache update of one decode / encode chunk in ONE launch (the `cache_front_feat` bookkeeping of
+ * CausalConv3d.forward, modeling_causal_conv.py:128-143): for buffer i (bf16 [2 + T][frame_elems[i]], HOST arrays of
+ * `count` <= 64 entries) the two leading cache slots receive the last two of the 2 + n_frames[i] frames. */
+int pf_shift_caches(int count, const void* const* bufs, const long long* frame_elems, const int* n_frames, pf_stream_t stream);
 /* latent z [C][T][H][W] fp32, frames t0..t0+nt, window (h0,w0,th,tw) -> channels-last bf16 with per-frame-class
  * affine (frame 0: a0 z + b0, others a1 z + b1: decode_latent un-normalisation, pipeline.py:1226-1230) */
 int pf_latent_to_nhwc(const float* z, void* y, int C, int T, int H, int W, int t0, int nt, int h0, int w0, int th,

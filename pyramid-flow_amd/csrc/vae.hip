@@ -287,6 +287,28 @@ __global__ __launch_bounds__(256) void rgb_to_yuv420_kernel(const unsigned char*
     vp[(long long)t * c_fs + r] = (unsigned char)min(max(cr, 0), 255);
 }
 
+// All cache-slot updates of one chunk in ONE launch (cache_front_feat update of every CausalConv3d,
+// modeling_causal_conv.py:132,143): buffer b: slots[0:2] <- frames [n, n+2) of slots[0 : 2+n)  (n >= 2), or
+// slot0 <- slot1, slot1 <- slot2 (n == 1).  blockIdx.y = buffer, 16-byte pieces over the 2 frames.
+struct ShiftList { int count; unsigned long long ptr[64]; long long fs[64]; int n[64]; };
+__global__ __launch_bounds__(256) void shift_caches_kernel(const ShiftList L) {
+    const int b = blockIdx.y;
+    if (b >= L.count) return;
+    u32x4_t* base = (u32x4_t*)L.ptr[b];
+    const long long fs8 = L.fs[b] >> 3;            // 16-byte pieces per frame
+    const int n = L.n[b];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < fs8; i += (long long)gridDim.x * blockDim.x) {
+        if (n >= 2) {
+            base[i] = base[(long long)n * fs8 + i];
+            base[fs8 + i] = base[(long long)(n + 1) * fs8 + i];
+        } else {
+            const u32x4_t v1 = base[fs8 + i], v2 = base[2 * fs8 + i];
+            base[i] = v1;
+            base[fs8 + i] = v2;
+        }
+    }
+}
+
 }  // namespace
 
 #define CHECK_LAUNCH()                                                  \
@@ -397,6 +419,27 @@ extern "C" int pf_rgb_to_yuv420(const void* rgb, void* y, void* u, void* v, int 
                        (const unsigned char*)rgb, (unsigned char*)y, (unsigned char*)u, (unsigned char*)v, T, H, W,
                        y_frame_stride ? y_frame_stride : (long long)H * W,
                        c_frame_stride ? c_frame_stride : (long long)(H / 2) * (W / 2));
+    CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pf_shift_caches(int count, const void* const* bufs, const long long* frame_elems, const int* n_frames,
+                               hipStream_t stream) {
+    if (count <= 0) return 0;
+    if (count > 64 || !bufs || !frame_elems || !n_frames) return pf_set_err("pf_shift_caches: 1..64 buffers");
+    ShiftList L;
+    L.count = count;
+    long long fs_max = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!bufs[i] || frame_elems[i] % 8 || n_frames[i] < 1) return pf_set_err("pf_shift_caches: bad entry");
+        L.ptr[i] = (unsigned long long)bufs[i];
+        L.fs[i] = frame_elems[i];
+        L.n[i] = n_frames[i];
+        fs_max = frame_elems[i] > fs_max ? frame_elems[i] : fs_max;
+    }
+    long long blocks = (fs_max / 8 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(shift_caches_kernel, dim3((unsigned)blocks, count), dim3(256), 0, stream, L);
     CHECK_LAUNCH();
     return 0;
 }

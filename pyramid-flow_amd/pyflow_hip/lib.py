@@ -66,7 +66,7 @@ EXPORTS = [
     "pf_last_error", "pf_version", "pf_gemm_bf16", "pf_gemm_set_policy", "pf_gemm_which", "pf_conv3d_bf16", "pf_attention_bf16", "pf_v_transpose",
     "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
     "pf_copy_rows", "pf_sp_relayout", "pf_renoise_upsample", "pf_avgpool2",
-    "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",
+    "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_shift_caches", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",
     "pf_embed_rows", "pf_rmsnorm", "pf_glu_mul", "pf_attention_small_bf16", "pf_rgb_to_yuv420",
     "pf_comm_unique_id", "pf_comm_init", "pf_comm_destroy", "pf_comm_rank", "pf_comm_world", "pf_all_to_all_v",
     "pf_halo_send_recv", "pf_all_gather_v", "pf_all_reduce_sum_f32", "pf_broadcast_bytes", "pf_comm_wait",

@@ -45,6 +45,7 @@ class PBuf:
             self.t = st[:n]
             self.t.zero_()
         self.cur = 0          # frames valid in slots [2, 2+cur)
+        self.pending = None   # list shared with the owning tile program: deferred cache-slot updates
         self.halo = None      # context-parallel mode: comm whose previous rank supplies the two cache slots
 
     def off(self, slot):
@@ -58,10 +59,16 @@ class PBuf:
         self.halo.shift(self.t[n * fs:(n + 2) * fs], self.t[0:2 * fs])
 
     def shift_cache(self):
-        """slots[0:2] <- last two of slots[0:2+cur]  (cache_front_feat update, causal_conv.py:132,143)."""
+        """slots[0:2] <- last two of slots[0:2+cur]  (cache_front_feat update, causal_conv.py:132,143).  Inside a tile
+        program the update is only RECORDED (`pending`): all buffers of a chunk are shifted by one pf_shift_caches launch
+        at the end of the chunk -- nothing reads the cache slots again before the next chunk."""
         if self.halo is not None:
             return            # context-parallel mode: one pass per rank, the slots are filled by exchange_halo()
         n = self.cur
+        if self.pending is not None:
+            if n >= 1:
+                self.pending.append((self, n))
+            return
         fs = self.fs
         if n >= 2:
             self.t[0:2 * fs].copy_(self.t[n * fs:(n + 2) * fs])
@@ -175,7 +182,11 @@ class _TileProgram:
                 if dn:
                     tf_ = (tf_ - 1) // 2 + 1
                     self.tmax.append(tf_)
-        self.stats = torch.zeros(max(self.tmax) * 512 * 2, dtype=torch.float64, device=self.dev)
+        # GroupNorm statistics: ONE arena with a region per norm layer, zeroed by one fill per chunk (the stats kernel
+        # accumulates atomically) instead of one fill per layer
+        self.stats = torch.zeros(40 * max(self.tmax) * 512 * 2, dtype=torch.float64, device=self.dev)
+        self._stats_regions, self._stats_used = {}, 0
+        self.pending = []           # (buffer, frames) cache-slot updates of the running chunk, flushed in one launch
         n = th * tw
         ca = vae.attn_pitch
         npad = _ru(n, 128)
@@ -191,6 +202,7 @@ class _TileProgram:
         if b is None:
             b = PBuf(name, self.tmax[level_t], H, W, Cc, self.dev, self.pool)
             b.halo = getattr(self, "halo", None)
+            b.pending = self.pending
             self.bufs[name] = b
         return b
 
@@ -205,13 +217,34 @@ class _TileProgram:
         for b in self.bufs.values():
             b.reset()
 
+    def begin_chunk(self):
+        self.stats[:max(self._stats_used, 1)].zero_() if self._stats_used else self.stats.zero_()
+        del self.pending[:]
+
+    def end_chunk(self):
+        """flush the recorded cache-slot updates: one launch for every buffer of the program"""
+        items = self.pending
+        lib = L.load()
+        for i0 in range(0, len(items), 64):
+            part = items[i0:i0 + 64]
+            k = len(part)
+            check(lib.pf_shift_caches(C.c_int(k), (C.c_void_p * k)(*[b.t.data_ptr() for b, _ in part]),
+                                      (C.c_longlong * k)(*[b.fs for b, _ in part]), (C.c_int * k)(*[n for _, n in part]),
+                                      stream()))
+        del self.pending[:]
+
     # ---- layer helpers -------------------------------------------------------------------------
     def gn(self, src, dst, name, silu=True, dst_raw=None):
         v = self.vae
         g, bt = v.norms[name]
         Tc = src.cur
-        st = self.stats[:Tc * src.C * 2]
-        st.zero_()
+        reg = self._stats_regions.get(name)
+        if reg is None:
+            size = max(self.tmax) * src.C * 2
+            assert self._stats_used + size <= self.stats.numel(), "GroupNorm statistics arena too small"
+            reg = self._stats_regions[name] = (self._stats_used, size)
+            self._stats_used += size
+        st = self.stats[reg[0]:reg[0] + Tc * src.C * 2]
         lib = L.load()
         nbytes = 2.0 * Tc * src.H * src.W * src.C                       # one pass over the activation (bf16)
         ops.PROFILER.launch("gn_stats", nbytes, lambda: check(lib.pf_gn_stats(
@@ -303,6 +336,7 @@ class _TileProgram:
         lat = cfg["latent_channels"]
         zb = self.buf("z", 0, th, tw, lat)
         lib = L.load()
+        self.begin_chunk()
         Zc, ZT, ZH, ZW = z.shape
         check(lib.pf_latent_to_nhwc(C.c_void_p(z.data_ptr()), C.c_void_p(zb.t.data_ptr()), C.c_int(Zc), C.c_int(ZT),
                                     C.c_int(ZH), C.c_int(ZW), C.c_int(t0), C.c_int(nt), C.c_int(h0), C.c_int(w0),
@@ -341,6 +375,7 @@ class _TileProgram:
         conv(n, None, v.convs["decoder.conv_out"], n.cur, dst_raw=(out_tile, x.H, x.W, 8, out_frame0))
         nf = n.cur
         n.shift_cache()
+        self.end_chunk()
         return nf
 
 
@@ -363,6 +398,7 @@ class _TileProgram:
         ph, pw = self.th * s_, self.tw * s_
         xin = self.buf("e.img", 0, ph, pw, 3)
         lib = L.load()
+        self.begin_chunk()
         Zc, ZT, ZH, ZW = img.shape
         check(lib.pf_latent_to_nhwc(C.c_void_p(img.data_ptr()), C.c_void_p(xin.t.data_ptr()), C.c_int(Zc), C.c_int(ZT),
                                     C.c_int(ZH), C.c_int(ZW), C.c_int(t0), C.c_int(T), C.c_int(h0), C.c_int(w0),
@@ -404,6 +440,10 @@ class _TileProgram:
         if chunked:
             n.shift_cache()
         conv(m, None, self.cw["quant_conv"], m.cur, dst_raw=(out_tile, x.H, x.W, out_tile.shape[-1], out_frame0))
+        if chunked:
+            self.end_chunk()
+        else:
+            del self.pending[:]          # a whole clip in one pass: the cache slots are not read again
         return m.cur
 
 
