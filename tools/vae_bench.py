@@ -3,6 +3,9 @@ reference mode tiled(256) / chunked(1).  usage: vae_bench.py [n_streams ...]"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+from pyflow_hip import lib as _lib
+if os.environ.get("PF_BENCH_LIB"):          # measurement only: A/B against another build of the library
+    _lib.LIB_PATH = os.path.join(ROOT, "pyramid-flow_amd", os.environ["PF_BENCH_LIB"])
 from pyflow_hip import synth, ops
 from pyflow_hip.vae import CausalVideoVAE
 dev = "cuda"
