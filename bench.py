@@ -393,15 +393,17 @@ def main():
         print(f"[bench] VAE kernel sample skipped: {e!r}", file=sys.stderr, flush=True)
     finally:
         ops.PROFILER.enabled = False
-    # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (one full-width forward at L = 15 488)
+    # L2 <-> fabric traffic per launch from the committed rocprofv3 --pmc passes (one full-width forward at L = 15 488)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_forward_maxL.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_forward_maxL.json")) as f:
             pm = json.load(f)["kernels"]
     except Exception:
         pm = {}
 
     def pmc_traffic(name):
-        key = {"attention": "attn_kernel", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name.split(">")[0] + ",")
+        key = {"attention": "attn_kernel", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
+        key = key.replace("gemm256_kernel<128>", "gemm256_kernel<128, false").replace("gemm256_kernel<192>", "gemm256_kernel<192, false") \
+                 .replace("gemm256_kernel<256>", "gemm256_kernel<256, false")
         for n, v in pm.items():
             if key in n:
                 return round(v["hbm_bytes_per_launch"])
@@ -411,7 +413,7 @@ def main():
             r["traffic"] = pmc_traffic(r["kernel"])
     if roof is not None and roof["traffic"] is not None:
         roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
-                                "the launches of one full-width forward at L=15488 (profiles/r01_pmc_forward_maxL.json); "
+                                "the launches of one full-width forward at L=15488 (profiles/r02_pmc_forward_maxL.json); "
                                 "counted at the L2<->fabric interface incl. Infinity-Cache hits")
     value = frames_per_video * args.steps * (1 if use_sp else world) / dt
     res = {

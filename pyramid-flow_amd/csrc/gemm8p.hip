@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     }
                     if (E_F32) {
                         const int m = wave_m0 + 16 * f + frow;
-                        if (m < p.M && ncol_ok[hsel] && p.diag != 1) {
+                        if (m < p.M && ncol_ok[hsel]) {
                             float* c = (float*)(c_row + ((long long)(16 * f) * p.ldc + n) * 4);
                             *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
                             *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
@@ -408,9 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
                     const int m = wave_m0 + 16 * f + frow;
-                    if (p.diag == 1) {
-                        asm volatile("" :: "v"(outp[hsel][f]));
-                    } else if (mapped) {
+                    if (mapped) {
                         long long coff;
                         const bool ok = out_off(m < p.M ? m : p.M - 1, ncol[hsel], coff) && m < p.M && ncol_ok[hsel];
                         if (ok) *(u32x4_t*)((bf16_t*)p.C + coff) = outp[hsel][f];
@@ -485,16 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
             // epilogue out of the counted waits
             PF_FENCE();
-            if (p.diag == 2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int f = 0; f < 8; ++f)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[f][j]));
-                acc_from_bias();
-            } else {
-                epilogue(c_tile);
-            }
+            epilogue(c_tile);
             PF_FENCE();
             skip_wait = 4;
             c_kt = 0;
@@ -540,10 +529,9 @@ bool pf_gemm8p_supports(const Args& a, bool conv) {
 }
 
 int pf_gemm8p_launch(const Args& a_in, bool conv, hipStream_t stream) {
-    Args a = a_in;
-    a.diag = 0;
+    const Args& a = a_in;
     const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
-    if (conv) return res ? launch<true, 1>(a, stream) : launch<true, 0>(a, stream);
+    if (conv) return launch<true, 0>(a, stream);          // conv + shortcut add stays on gemm256 (pf_gemm8p_supports)
     if (res) return launch<false, 1>(a, stream);
     if (f32) return launch<false, 2>(a, stream);
     if (act) return launch<false, 4>(a, stream);

@@ -34,7 +34,6 @@ struct Args {
     int gelu_from, flags, n_valid;
     float out_scale;
     int group_m;             // M-tiles per L2 super-tile of the 256-row kernels (tile order; 0 = default)
-    int diag;                // lab builds only: 1 = epilogue without global stores, 2 = no epilogue
     ConvGeom cg; OutMap om;
 };
 
