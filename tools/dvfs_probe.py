@@ -2,10 +2,23 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 from pyflow_hip import ops
 from pyflow_hip.plan import SequencePlan
-from microbench import timeit
+
+
+def timeit(fn, iters=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 B, H, Lt, d = 2, 30, 128, 1920
 clips = [(28, 24, 40), (1, 48, 80), (1, 96, 160), (1, 96, 160)]
 mask = torch.zeros(B, Lt, dtype=torch.long); mask[0, :40] = 1; mask[1, :96] = 1
