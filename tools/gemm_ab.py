@@ -9,6 +9,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+from pyflow_hip import lib as _lib                                                            # noqa: E402
+if os.environ.get("PF_BENCH_LIB"):          # measurement only (a switch of this TOOL): A/B against another build of the library
+    _lib.LIB_PATH = os.path.join(ROOT, "pyramid-flow_amd", os.environ["PF_BENCH_LIB"])
 from pyflow_hip import ops                                                                    # noqa: E402
 
 SHAPES = [  # (M per batch, batch, N, K, gelu_from, gate_res)
@@ -33,7 +36,10 @@ def timed(fn, iters):
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     g = torch.Generator(device="cuda").manual_seed(0)
-    for M, B, N, K, gf, gr in SHAPES:
+    shapes = SHAPES
+    if os.environ.get("GEMM_AB_SHAPES"):
+        shapes = [SHAPES[int(i)] for i in os.environ["GEMM_AB_SHAPES"].split(",")]
+    for M, B, N, K, gf, gr in shapes:
         A = torch.randn(B, M, K, device="cuda", generator=g).bfloat16()
         W = (torch.randn(N, K, device="cuda", generator=g) * 0.02).bfloat16()
         bias = torch.randn(N, device="cuda", generator=g)
