@@ -240,8 +240,6 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
     if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
     const int bn256 = pf_gemm256_pick((long long)d->M * d->batch, d->M, d->batch, d->N, gemm256_force());
-    if (!bn256 && d->N % BN != 0 && !use_gemm8p(d->M, d->batch, d->N, d->K))
-        return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (d->K % BK != 0 || d->K <= 0) return set_err("pf_gemm_bf16: K must be a positive multiple of 64");
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8)) return set_err("pf_gemm_bf16: leading dims must be multiples of 8");
     if ((d->flags & PF_GEMM_GATE_RES) && !d->res) return set_err("pf_gemm_bf16: GATE_RES needs res");
@@ -254,7 +252,10 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     a.out_scale = 1.f; a.n_valid = d->N;
     if (a.gelu_from % 8) return set_err("pf_gemm_bf16: gelu_from must be a multiple of 8");
     a.group_m = 0;
-    if (use_gemm8p(d->M, d->batch, d->N, d->K) && pf_gemm8p_supports(a, false)) {
+    const bool g8 = use_gemm8p(d->M, d->batch, d->N, d->K) && pf_gemm8p_supports(a, false);
+    if (!g8 && !bn256 && d->N % BN != 0)
+        return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
+    if (g8) {
         pf_gemm8p_launch(a, false, stream);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));

@@ -330,7 +330,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         for (int hsel = 0; hsel < 2; ++hsel) {
             if (E_RES) load_col_params(hsel);
             const int n = ncol[hsel];
-            const bool do_act = E_ACT && (wave_n0 + 32 * hsel + 8 * fq) >= p.gelu_from;
+            // wave-uniform (gelu_from is a multiple of 32, pf_gemm8p_supports): the column halves left of gelu_from skip
+            // the activation's VALU work instead of computing and discarding it
+            const bool do_act = E_ACT && (wave_n0 + 32 * hsel) >= p.gelu_from;
 #pragma unroll
             for (int f0 = 0; f0 < 8; f0 += FB) {
                 u32x4_t rbuf[FB];
@@ -369,11 +371,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         }
                     }
                     if (E_ACT) {
-                        float a8[8];
+                        if (do_act) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) a8[e] = gelu_tanh(v[e]);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = do_act ? a8[e] : v[e];
+                            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                        }
                     }
                     if (E_RES) {
                         float rv[8];
@@ -525,6 +526,7 @@ bool pf_gemm8p_supports(const Args& a, bool conv) {
     const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
     if ((int)res + (int)f32 + (int)act > 1) return false;
     if (conv && (f32 || act || res)) return false;      // conv + shortcut add: the instantiation spills (kept on gemm256)
+    if (act && (a.gelu_from & 31)) return false;        // the activation is decided per 32-column half of a wave tile
     return true;
 }
 
