@@ -453,6 +453,9 @@ def main():
                                      + ("temporal context-parallel un-tiled decode (halo exchange per causal conv, uneven frame ranges)"
                                         if (vae_only and use_cp) else "tiled(256) / chunked(1) decode, four chunk windows per launch set"
                                         + (", tile columns split over the ranks" if world > 1 else "")))
+        if world > 1:
+            res["config"]["parallelism"] = (f"cp{world}: temporal context-parallel decode over {world} GPUs" if use_cp
+                                            else f"{world} GPUs, tile columns of the tiled decode split over the ranks")
         conv = extra.get("vae:conv3d") or {}
         res["roofline"] = dict(conv, note="dominant kernel family of the decode: implicit-GEMM CausalConv3d (MFMA-bound for C >= 128); "
                                           "GroupNorm passes against the HBM peak in roofline_other_kernels") if conv else None
