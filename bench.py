@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--tiny-model", action="store_true", help="tiny random model (plumbing check, not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-period", type=int, default=7)
+    ap.add_argument("--launch-mode", default="graph", choices=["eager", "list", "graph"],
+                    help="how the DiT's launches reach the device (pyflow_hip/cmdlist.py); default = the engine's default")
     ap.add_argument("--parallelism", default="sp", choices=["sp", "replicas"],
                     help="N > 1: sp = one video across all GPUs (default), replicas = one video per GPU")
     args = ap.parse_args()
@@ -295,6 +297,8 @@ def main():
         pipe, dcfg, dsd = build_pipeline(device, tiny=args.tiny_model, mmdit=i2v, stages=1 if image_only else None)
         embeds = synthetic_prompt(dcfg, device)
         image = torch.randn(3, H, W, generator=torch.Generator().manual_seed(77)).clamp(-1, 1)
+        if hasattr(pipe.dit, "launch_mode"):
+            pipe.dit.launch_mode = args.launch_mode
         sp = SampledProfiler(pipe, args.profile_period)
 
         def one_video(seed):
@@ -435,6 +439,8 @@ def main():
         "roofline": roof,
         "roofline_other_kernels": extra,
     }
+    if pipe is not None:
+        res["config"]["launch_mode"] = getattr(pipe.dit, "launch_mode", "eager")
     if i2v:
         res["metric"] = "video frames/sec for 768p image-to-video sampling (config C4, not the headline metric)"
         res["config"]["workload"] = (f"{args.workload}: SD3-style MMDiT (24 joint blocks, d=1536) generate_i2v + CausalVideoVAE "

@@ -258,6 +258,45 @@ int pf_all_reduce_sum_f32(pf_comm* c, float* buf, long long count, pf_stream_t c
 int pf_broadcast_bytes(pf_comm* c, void* buf, long long bytes, int root, pf_stream_t compute);
 int pf_comm_wait(pf_comm* c, pf_stream_t stream);
 
+/* ------------------------------------------------------------------ launch lists ------------------
+ * The kernel sequence of one transformer forward, recorded once per (unit, stage) and re-issued from C: the reference
+ * calls the transformer 10-20 times per pyramid stage with identical shapes, buffers and weights
+ * (pyramid_dit_for_video_gen_pipeline.py:611-660); the host cost of those ~300 launches per forward (and, sequence
+ * parallel, of ~50 communicator calls: trainer_misc/communicate.py:7-26 inside flux_block.py:266-325) moves from the
+ * interpreter into one call.  pf_cmdlist_<op> takes the arguments of pf_<op> with the list in front and, instead of the
+ * stream, a stream SLOT: 0 = the compute stream, 1 = the side stream given to pf_cmdlist_run; pf_cmdlist_join(l, from, to)
+ * makes slot `to` wait for everything recorded so far on slot `from`.  pf_cmdlist_run issues the entries in order through
+ * the same entry points (bit-identical to the eager sequence).  pf_cmdlist_instantiate captures that replay into a
+ * hipGraph (lists without communicator entries; every side-stream entry must have been joined back to slot 0), after
+ * which pf_cmdlist_run is one hipGraphLaunch; the pointers recorded in a list must stay valid while it is in use. */
+typedef struct pf_cmdlist pf_cmdlist;
+pf_cmdlist* pf_cmdlist_create(void);
+int pf_cmdlist_destroy(pf_cmdlist* l);
+int pf_cmdlist_clear(pf_cmdlist* l);
+int pf_cmdlist_size(const pf_cmdlist* l);
+int pf_cmdlist_is_graph(const pf_cmdlist* l);
+int pf_cmdlist_gemm(pf_cmdlist* l, const pf_gemm_desc* d, int slot);
+int pf_cmdlist_attention(pf_cmdlist* l, const pf_attn_desc* d, int slot);
+int pf_cmdlist_ln_modulate(pf_cmdlist* l, const void* x, void* y, const float* shift, const float* scale, int D, int B,
+                           int rows_per_batch, long long x_bstride, long long y_bstride, int ldx, int ldy, int mod_bstride,
+                           float eps, int slot);
+int pf_cmdlist_qk_norm_rope(pf_cmdlist* l, void* qkv, int ld, long long bstride, int q_off, int k_off, const float* wq_img,
+                            const float* wk_img, const float* wq_txt, const float* wk_txt, const float* rope, int B, int L,
+                            int Lt, int H, float eps, float q_scale, int head_stride, int slot);
+int pf_cmdlist_v_transpose(pf_cmdlist* l, const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b,
+                           long long strideVt_h, int B, int H, int L, int Lp, int head_stride, int slot);
+int pf_cmdlist_sp_relayout(pf_cmdlist* l, void* mat, void* chunks, int rows, int B, int ld, long long mat_bstride, int n_parts,
+                           const int* col0, const int* cols, const long long* off, int to_chunks, int slot);
+int pf_cmdlist_copy_rows(pf_cmdlist* l, const void* src, void* dst, int rows, int D, int ld_src, int ld_dst,
+                         long long src_bstride, long long dst_bstride, int B, int slot);
+int pf_cmdlist_all_to_all_v(pf_cmdlist* l, pf_comm* c, const void* send, const long long* send_bytes,
+                            const long long* send_offs, void* recv, const long long* recv_bytes, const long long* recv_offs,
+                            int slot);
+int pf_cmdlist_comm_wait(pf_cmdlist* l, pf_comm* c, int slot);
+int pf_cmdlist_join(pf_cmdlist* l, int from_slot, int to_slot);
+int pf_cmdlist_run(pf_cmdlist* l, pf_stream_t compute, pf_stream_t side);
+int pf_cmdlist_instantiate(pf_cmdlist* l, pf_stream_t compute, pf_stream_t side);
+
 #ifdef __cplusplus
 }
 #endif

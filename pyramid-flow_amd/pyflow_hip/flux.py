@@ -201,6 +201,11 @@ class FluxEngine(DeviceModuleAPI):
         self.overlap_text = True        # text stream of the double blocks on a side HIP stream
         self.skip_dead_rows = True      # last block: Q / MLP / attention / proj_out only for the current frame's rows
         self._side = None
+        # how the ~300 launches of the blocks + head of one forward reach the device (cmdlist.py):
+        #   "eager": one ctypes call per launch;  "list": recorded once per plan, re-issued from C by one call;
+        #   "graph": the same list captured into a hipGraph after its first replay (one hipGraphLaunch per forward)
+        self.launch_mode = "graph"
+        self._ws_gen = 0                # bumped when a workspace buffer is re-allocated (recorded pointers go stale)
 
     def _side_stream(self):
         if self._side is None:
@@ -214,6 +219,7 @@ class FluxEngine(DeviceModuleAPI):
             t = torch.zeros(numel, dtype=dtype, device=self.dev) if name == "vT" \
                 else torch.empty(numel, dtype=dtype, device=self.dev)
             self._ws[name] = t
+            self._ws_gen += 1
         return t
 
     def make_plan(self, clip_shapes, enc_mask):
@@ -299,8 +305,61 @@ class FluxEngine(DeviceModuleAPI):
         ctx = ctx if ctx is not None else self._ctx
         mod, _ = self.conditioning(timesteps, pooled)
         self._embed_tokens(plan, clips, ctx, shared_clips, debug)
-        self._run_blocks(plan, mod, debug=debug)
-        return self._head(plan, mod)
+        if self.launch_mode == "eager" or debug is not None or ops.PROFILER.enabled:
+            self._run_blocks(plan, mod, debug=debug)
+            return self._head(plan, mod)
+        return self._run_launch_list(plan, mod)
+
+    def _run_launch_list(self, plan, mod):
+        """blocks + head through the plan's launch list: every step of a (unit, stage) runs the same kernels on the same
+        buffers -- only the CONTENT of the modulation vector (copied into a fixed buffer first) and of `hidden` differs."""
+        from .cmdlist import CommandList, recording
+        w = self.w
+        n_mod = plan.B * w.n_mod
+        for _ in range(2):
+            ms = self._buf("mod_fixed", n_mod, torch.float32)
+            key = (id(self), self._ws_gen, self.overlap_text, self.skip_dead_rows, self.launch_mode != "list")
+            ent = getattr(plan, "_launch_list", None)
+            if ent is not None and ent[0] == key:
+                break
+            cl = CommandList()
+            with recording(cl):
+                self._run_blocks(plan, ms)
+                out = self._head(plan, ms)
+            if key[1] != self._ws_gen:        # a workspace buffer was (re)allocated while recording: pointers of the
+                continue                      # earlier entries may be stale -> record again, now without allocations
+            plan._launch_list = ent = (key, cl, out)
+            break
+        else:
+            raise RuntimeError("launch list: the workspace did not settle")
+        _, cl, out = ent
+        ms = self._ws["mod_fixed"]
+        ms[:n_mod].copy_(mod.reshape(-1)[:n_mod])
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_text else main
+        if self.launch_mode == "graph" and cl.runs >= 1 and not cl.is_graph:
+            # after one plain replay (every lazy one-time set-up has happened eagerly).  Captured on two private
+            # streams -- torch's default stream is the legacy stream, which cannot be captured; the graph is then
+            # launched on the caller's stream like any kernel.
+            if getattr(self, "_cap_streams", None) is None:
+                self._cap_streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            try:
+                cl.instantiate(*self._cap_streams)
+            except RuntimeError as e:         # no graph support for this sequence on this stack: keep replaying the list
+                import warnings
+                warnings.warn(f"launch list: hipGraph capture failed ({e}); falling back to list replay")
+                self.launch_mode = "list"
+        try:
+            cl.run(main, side)
+        except RuntimeError:
+            if not cl.is_graph:
+                raise
+            import warnings                   # a graph launch failed: drop to list replay for the rest of the run
+            warnings.warn("launch list: hipGraphLaunch failed; falling back to list replay")
+            self.launch_mode = "list"
+            del plan._launch_list
+            return self._run_launch_list(plan, mod)
+        return out
 
     def _geometry(self, plan):
         w = self.w
@@ -361,11 +420,23 @@ class FluxEngine(DeviceModuleAPI):
         # the image GEMMs' tails leave idle.  Rows / buffer regions of the two streams are disjoint.
         main = torch.cuda.current_stream()
         side = self._side_stream() if (self.overlap_text and dbl) else None
-        if side is not None:
-            side.wait_stream(main)
+        rec = ops.RECORDER                # recording a launch list: stream switches / joins become list entries
+
+        def join(frm, to):
+            """stream slot `to` (0 = main, 1 = side) waits for the work queued so far on slot `frm`"""
+            if side is None:
+                return
+            if rec is not None:
+                rec.join(frm, to)
+            else:
+                (side if to else main).wait_stream(main if to else side)
 
         def on_side():
-            return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+            if side is None:
+                return contextlib.nullcontext()
+            return rec.on_slot(1) if rec is not None else torch.cuda.stream(side)
+
+        join(0, 1)
 
         n_cur = plan.n_cur
         for blk in dbl:
@@ -392,15 +463,13 @@ class FluxEngine(DeviceModuleAPI):
             else:
                 ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
                          strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d)
-            if side is not None:
-                main.wait_stream(side)
+            join(1, 0)
             ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
                              blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
             ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
                           q_row_begin=r0 if tail else 0)
-            if side is not None:
-                side.wait_stream(main)
+            join(0, 1)
             if not pre_only:
                 with on_side():
                     ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
@@ -422,11 +491,9 @@ class FluxEngine(DeviceModuleAPI):
                      res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                      gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + r0 * 4 * d, c_off=r0 * d, r_off=r0 * d)
             if debug is not None and "hidden_d0" not in debug:
-                if side is not None:
-                    main.wait_stream(side)
+                join(1, 0)
                 debug["hidden_d0"] = hidden[:B * L * d].view(B, L, d).clone()
-        if side is not None:
-            main.wait_stream(side)
+        join(1, 0)
 
         n_cur = plan.n_cur
         for bi, blk in enumerate(sgl):

@@ -70,6 +70,10 @@ EXPORTS = [
     "pf_embed_rows", "pf_rmsnorm", "pf_glu_mul", "pf_attention_small_bf16", "pf_rgb_to_yuv420",
     "pf_comm_unique_id", "pf_comm_init", "pf_comm_destroy", "pf_comm_rank", "pf_comm_world", "pf_all_to_all_v",
     "pf_halo_send_recv", "pf_all_gather_v", "pf_all_reduce_sum_f32", "pf_broadcast_bytes", "pf_comm_wait",
+    "pf_cmdlist_create", "pf_cmdlist_destroy", "pf_cmdlist_clear", "pf_cmdlist_size", "pf_cmdlist_is_graph", "pf_cmdlist_gemm",
+    "pf_cmdlist_attention", "pf_cmdlist_ln_modulate", "pf_cmdlist_qk_norm_rope", "pf_cmdlist_v_transpose",
+    "pf_cmdlist_sp_relayout", "pf_cmdlist_copy_rows", "pf_cmdlist_all_to_all_v", "pf_cmdlist_comm_wait", "pf_cmdlist_join",
+    "pf_cmdlist_run", "pf_cmdlist_instantiate",
 ]
 
 
@@ -89,6 +93,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.pf_last_error.restype = C.c_char_p
     lib.pf_version.restype = C.c_int
+    lib.pf_cmdlist_create.restype = C.c_void_p
     _lib = lib
     return lib
 

@@ -39,6 +39,9 @@ class KernelProfiler:
 
 
 PROFILER = KernelProfiler()
+RECORDER = None      # a cmdlist.CommandList while a launch list is being recorded (cmdlist.recording): the recordable
+                     # wrappers below append to it instead of launching
+
 
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
@@ -57,6 +60,10 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr = M, N, K, lda, ldw, ldc, ldr
     d.strideA, d.strideC, d.strideR = strideA, strideC, strideR
     d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
+    rec = RECORDER
+    if rec is not None:
+        check(lib.pf_cmdlist_gemm(rec.h, C.byref(d), C.c_int(rec.slot)))
+        return
     if PROFILER.enabled:      # attribute the launch to the kernel rocprofv3 will name
         bn = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K))
         if bn == 8:       # the epilogue flavour is a template argument: same names as in a rocprofv3 kernel trace
@@ -102,15 +109,21 @@ def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt,
     d.tile_kv_end = plan.tile_kv_end.data_ptr()
     d.scale = scale
     d.q_prescaled = int(q_prescaled)
+    rec = RECORDER
+    if rec is not None:
+        check(lib.pf_cmdlist_attention(rec.h, C.byref(d), C.c_int(rec.slot)))
+        return
     PROFILER.launch("attention", 4.0 * plan.useful_pairs(q_row_begin) * 64 * H,
                     lambda: check(lib.pf_attention_bf16(C.byref(d), stream())))
 
 
 def v_transpose(V, Vt, v_off, ldv, strideV, B, H, Lseq, Lp, head_stride=0):
     lib = L.load()
-    check(lib.pf_v_transpose(C.c_void_p(V.data_ptr() + 2 * v_off), ptr(Vt), C.c_int(ldv), C.c_longlong(strideV),
-                             C.c_longlong(H * 64 * Lp), C.c_longlong(64 * Lp), C.c_int(B), C.c_int(H),
-                             C.c_int(Lseq), C.c_int(Lp), C.c_int(head_stride), stream()))
+    rec = RECORDER
+    fn, head, tail = (lib.pf_v_transpose, (), (stream(),)) if rec is None else (lib.pf_cmdlist_v_transpose, (rec.h,), (C.c_int(rec.slot),))
+    check(fn(*head, C.c_void_p(V.data_ptr() + 2 * v_off), ptr(Vt), C.c_int(ldv), C.c_longlong(strideV),
+             C.c_longlong(H * 64 * Lp), C.c_longlong(64 * Lp), C.c_int(B), C.c_int(H),
+             C.c_int(Lseq), C.c_int(Lp), C.c_int(head_stride), *tail))
 
 
 def ln_modulate(x, y, shift, scale, D, B, rows, x_bstride, y_bstride, ldx, ldy, mod_bstride,
@@ -119,18 +132,22 @@ def ln_modulate(x, y, shift, scale, D, B, rows, x_bstride, y_bstride, ldx, ldy, 
     lib = L.load()
     sh = C.c_void_p(shift[0].data_ptr() + 4 * shift[1])
     sc = C.c_void_p(scale[0].data_ptr() + 4 * scale[1])
-    check(lib.pf_ln_modulate(C.c_void_p(x.data_ptr() + 2 * x_off), C.c_void_p(y.data_ptr() + 2 * y_off), sh, sc,
-                             C.c_int(D), C.c_int(B), C.c_int(rows), C.c_longlong(x_bstride),
-                             C.c_longlong(y_bstride), C.c_int(ldx), C.c_int(ldy), C.c_int(mod_bstride),
-                             C.c_float(eps), stream()))
+    rec = RECORDER
+    fn, head, tail = (lib.pf_ln_modulate, (), (stream(),)) if rec is None else (lib.pf_cmdlist_ln_modulate, (rec.h,), (C.c_int(rec.slot),))
+    check(fn(*head, C.c_void_p(x.data_ptr() + 2 * x_off), C.c_void_p(y.data_ptr() + 2 * y_off), sh, sc,
+             C.c_int(D), C.c_int(B), C.c_int(rows), C.c_longlong(x_bstride),
+             C.c_longlong(y_bstride), C.c_int(ldx), C.c_int(ldy), C.c_int(mod_bstride),
+             C.c_float(eps), *tail))
 
 
 def qk_norm_rope(qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt, wk_txt, rope, B, Lseq, Lt, H, eps=1e-6,
                  q_scale=1.0, head_stride=0):
     lib = L.load()
-    check(lib.pf_qk_norm_rope(ptr(qkv), C.c_int(ld), C.c_longlong(bstride), C.c_int(q_off), C.c_int(k_off),
-                              ptr(wq_img), ptr(wk_img), ptr(wq_txt), ptr(wk_txt), ptr(rope), C.c_int(B),
-                              C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), C.c_float(q_scale), C.c_int(head_stride), stream()))
+    rec = RECORDER
+    fn, head, tail = (lib.pf_qk_norm_rope, (), (stream(),)) if rec is None else (lib.pf_cmdlist_qk_norm_rope, (rec.h,), (C.c_int(rec.slot),))
+    check(fn(*head, ptr(qkv), C.c_int(ld), C.c_longlong(bstride), C.c_int(q_off), C.c_int(k_off),
+             ptr(wq_img), ptr(wk_img), ptr(wq_txt), ptr(wk_txt), ptr(rope), C.c_int(B),
+             C.c_int(Lseq), C.c_int(Lt), C.c_int(H), C.c_float(eps), C.c_float(q_scale), C.c_int(head_stride), *tail))
 
 
 def gemv(W, bias, x, y, N, K, B, ldw=None, ldx=None, ldy=None, silu_in=False, accumulate=False, y_off=0):
@@ -162,18 +179,22 @@ def cfg_euler_step(v, vb_stride, ld, x, Cc, H, W, guidance, use_cfg, dsigma, rou
 
 def copy_rows(src, dst, rows, D, ld_src, ld_dst, src_bstride, dst_bstride, B, dst_off=0, src_off=0):
     lib = L.load()
-    check(lib.pf_copy_rows(C.c_void_p(src.data_ptr() + 2 * src_off), C.c_void_p(dst.data_ptr() + 2 * dst_off),
-                           C.c_int(rows), C.c_int(D), C.c_int(ld_src), C.c_int(ld_dst), C.c_longlong(src_bstride),
-                           C.c_longlong(dst_bstride), C.c_int(B), stream()))
+    rec = RECORDER
+    fn, head, tail = (lib.pf_copy_rows, (), (stream(),)) if rec is None else (lib.pf_cmdlist_copy_rows, (rec.h,), (C.c_int(rec.slot),))
+    check(fn(*head, C.c_void_p(src.data_ptr() + 2 * src_off), C.c_void_p(dst.data_ptr() + 2 * dst_off),
+             C.c_int(rows), C.c_int(D), C.c_int(ld_src), C.c_int(ld_dst), C.c_longlong(src_bstride),
+             C.c_longlong(dst_bstride), C.c_int(B), *tail))
 
 
 def sp_relayout(mat, chunks, rows, B, ld, mat_bstride, col0, cols, off, to_chunks, mat_off=0):
     """pack (to_chunks) / unpack the all-to-all chunks; col0 / cols / off: per-part python lists (elements)."""
     lib = L.load()
     n = len(cols)
-    check(lib.pf_sp_relayout(C.c_void_p(mat.data_ptr() + 2 * mat_off), ptr(chunks), C.c_int(rows), C.c_int(B), C.c_int(ld),
-                             C.c_longlong(mat_bstride), C.c_int(n), (C.c_int * n)(*col0), (C.c_int * n)(*cols),
-                             (C.c_longlong * n)(*off), C.c_int(int(to_chunks)), stream()))
+    rec = RECORDER
+    fn, head, tail = (lib.pf_sp_relayout, (), (stream(),)) if rec is None else (lib.pf_cmdlist_sp_relayout, (rec.h,), (C.c_int(rec.slot),))
+    check(fn(*head, C.c_void_p(mat.data_ptr() + 2 * mat_off), ptr(chunks), C.c_int(rows), C.c_int(B), C.c_int(ld),
+             C.c_longlong(mat_bstride), C.c_int(n), (C.c_int * n)(*col0), (C.c_int * n)(*cols),
+             (C.c_longlong * n)(*off), C.c_int(int(to_chunks)), *tail))
 
 
 def renoise_upsample(xin, noise, xout, Cc, H, W, alpha, beta, round_bf16):

@@ -47,3 +47,23 @@ def test_missing_library_fails_loudly(monkeypatch):
     import pytest
     with pytest.raises(lib.PyflowLibraryMissing):
         lib.load()
+
+
+def test_launch_list_bookkeeping_without_a_device():
+    """recording needs no GPU: entries are descriptors; errors come back through pf_last_error"""
+    import ctypes as C
+    from pyflow_hip import lib as L
+    from pyflow_hip.lib import GemmDesc, AttnDesc
+    lib = L.load()
+    h = C.c_void_p(lib.pf_cmdlist_create())
+    assert h.value
+    assert lib.pf_cmdlist_size(h) == 0 and lib.pf_cmdlist_is_graph(h) == 0
+    assert lib.pf_cmdlist_gemm(h, C.byref(GemmDesc()), C.c_int(0)) == 0
+    assert lib.pf_cmdlist_attention(h, C.byref(AttnDesc()), C.c_int(1)) == 0
+    assert lib.pf_cmdlist_size(h) == 2
+    assert lib.pf_cmdlist_gemm(h, C.byref(GemmDesc()), C.c_int(2)) != 0
+    assert b"slot" in lib.pf_last_error()
+    assert lib.pf_cmdlist_gemm(h, None, C.c_int(0)) != 0
+    assert lib.pf_cmdlist_join(h, C.c_int(0), C.c_int(0)) != 0
+    assert lib.pf_cmdlist_clear(h) == 0 and lib.pf_cmdlist_size(h) == 0
+    assert lib.pf_cmdlist_destroy(h) == 0

@@ -15,8 +15,9 @@ for k, shp in synth.flux_param_shapes(cfg).items():
 mask = torch.zeros(2, 128, dtype=torch.long); mask[0, :40] = 1; mask[1, :96] = 1
 enc = torch.randn(2, 128, 4096).to(torch.bfloat16)
 pooled = torch.randn(2, 768)
-for cls in (FluxEngine, FluxEngineSP):
+for cls, mode in ((FluxEngine, "eager"), (FluxEngine, "list"), (FluxEngine, "graph"), (FluxEngineSP, "eager")):
     eng = cls(sd, cfg, dev)
+    eng.launch_mode = mode
     eng.encode_context(enc)
     for name, shapes in {"u1s0": [(1, 24, 40), (1, 24, 40)], "u5s1": [(4, 24, 40), (1, 48, 80), (1, 48, 80)]}.items():
         clips = [torch.randn(1, 16, *s, device=dev) for s in shapes]
@@ -31,6 +32,6 @@ for cls in (FluxEngine, FluxEngineSP):
         t_host = (time.perf_counter() - t0) / n
         torch.cuda.synchronize()
         t_all = (time.perf_counter() - t0) / n
-        print(f"{cls.__name__} {name} L={plan.L}: host launch loop {t_host * 1e3:.2f} ms / forward, wall {t_all * 1e3:.2f} ms / forward", flush=True)
+        print(f"{cls.__name__} [{mode}] {name} L={plan.L}: host launch loop {t_host * 1e3:.2f} ms / forward, wall {t_all * 1e3:.2f} ms / forward", flush=True)
     del eng
     torch.cuda.empty_cache()
