@@ -48,6 +48,13 @@ typedef struct {
     int M, N, K, lda, ldw, ldc, ldr;
     long long strideA, strideC, strideR;
     int gate_stride, batch, gelu_from, flags;
+    /* optional scratch for SKINNY problems (fewer than 128 tiles of 128 x 128, e.g. the 128-token text stream of the
+     * double blocks, flux_block.py:816-835 / 42-100, and the prompt encoders): with it the K range is split over
+     * ceil(256 / tiles) workgroups per tile (fp32 partial sums [split][batch][M][N] in the scratch, summed in split order
+     * by a second launch that applies the epilogue), which turns one workgroup's chain of K / 64 dependent memory
+     * latencies into several short ones.  NULL / 0 = never split.  Must not be shared by launches that may overlap. */
+    void* workspace;
+    long long workspace_bytes;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
 /* Kernel selection for pf_gemm_bf16 / pf_conv3d_bf16 (test hook; results are identical up to fp32 summation order).
@@ -55,7 +62,7 @@ int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
  * else the 256 x BN ping-pong kernel (BN = 256 / 192 / 128) when it yields >= 192 tiles, else the 128 x 128 kernel;
  * -1 = always the 128 x 128 kernel; 128 / 192 / 256 = force the 256 x BN kernel whenever BN divides N;
  * 8 = force gemm8p whenever its epilogue flavour exists (bias + ONE of residual / fp32 output / GELU-tanh); -8 = never
- * gemm8p.  Default 0. */
+ * gemm8p; -2 / 2 = never / again split K for skinny problems that bring a workspace.  Default 0. */
 int pf_gemm_set_policy(int force);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =
  * gemm8p_kernel, BN > 0 = gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */

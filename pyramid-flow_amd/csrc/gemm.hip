@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
     const int per_batch = tiles_n * tiles_m;
-    const int nwg = per_batch * p.batch;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int nwg = per_batch * p.batch * ksplit;
     int t = xcd_remap(blockIdx.x, nwg);
+    const int ks_id = t / (per_batch * p.batch);        // which part of the K range this workgroup sums (split-K)
+    t -= ks_id * per_batch * p.batch;
     const int b = t / per_batch;
     t -= b * per_batch;
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
@@ -98,12 +101,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
     const int a_row_off = (wm * 64 + frow) * 128;
     const int w_row_off = (wn * 64 + frow) * 128;
 
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    const int kt_begin = (int)((long long)nk * ks_id / ksplit), kt_end = (int)((long long)nk * (ks_id + 1) / ksplit);
+    issue(kt_begin, 0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
         const char* sa = smem + buf * BUF_BYTES;
         const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -138,6 +142,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
     __syncthreads();
     const int col = (tid & 15) * 8;
     const int n = n0 + col;
+    if (!CONV && ksplit > 1) {          // split-K: raw partial sums; splitk_epilogue_kernel adds them up in split order
+        float* part = p.part + ((long long)(ks_id * p.batch + b) * p.M) * p.N;
+#pragma unroll 2
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            float* c = part + (long long)m * p.N + n;
+            *(f32x4_t*)c = *(const f32x4_t*)(st + row * BN + col);
+            *(f32x4_t*)(c + 4) = *(const f32x4_t*)(st + row * BN + col + 4);
+        }
+        return;
+    }
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = p.bias ? p.bias[n + e] : 0.f;
@@ -199,6 +216,48 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
     }
 }
 
+// second launch of a split-K GEMM: C = epi(sum over the splits, in split order, of the fp32 partial sums) -- the same
+// epilogue arithmetic as gemm_kernel's.  One thread per (row, 8 columns).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const Args p) {
+    const int chunks = p.N >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.batch * p.M * chunks;
+    if (idx >= total) return;
+    const int ck = (int)(idx % chunks);
+    const long long rowi = idx / chunks;
+    const int m = (int)(rowi % p.M), b = (int)(rowi / p.M);
+    const int n = ck * 8;
+    if (n >= p.n_valid) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int s_ = 0; s_ < p.ksplit; ++s_) {
+        const float* c = p.part + (((long long)(s_ * p.batch + b) * p.M) + m) * p.N + n;
+        const f32x4_t v0 = *(const f32x4_t*)c, v1 = *(const f32x4_t*)(c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += v0[e]; v[4 + e] += v1[e]; }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+    }
+    if (n >= p.gelu_from) act8(v, p.flags);
+    const long long coff = (long long)b * p.sC + (long long)m * p.ldc + n;
+    if (p.flags & PF_GEMM_GATE_RES) {
+        float rv[8];
+        unpack8(*(const u32x4_t*)(p.res + (long long)b * p.sR + (long long)m * p.ldr + n), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rv[e] + (p.gate ? p.gate[(long long)b * p.gate_stride + n + e] : 1.f) * v[e];
+    }
+    if (p.flags & PF_GEMM_OUT_F32) {
+        float* c = (float*)p.C + coff;
+        *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+    } else {
+        *(u32x4_t*)((bf16_t*)p.C + coff) = pack8(v);
+    }
+}
+
 }  // namespace
 
 int pf_set_err(const char* m);
@@ -213,6 +272,7 @@ static int g_gemm256_force = 0;
 static int gemm256_force() { return g_gemm256_force; }
 // gemm8p (persistent 256 x 256 tiles): 1 = whenever legal (policy 8), 0 = automatic, -1 = never (policy -8)
 static int g_gemm8p_mode = 0;
+static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
 static bool use_gemm8p(int M, int batch, int N, int K) {
     if (g_gemm8p_mode < 0 || N % 8 || K % 64) return false;
@@ -226,10 +286,12 @@ static bool use_gemm8p(int M, int batch, int N, int K) {
 }
 extern "C" int pf_gemm_set_policy(int force) {
     if (force == 8 || force == -8) { g_gemm8p_mode = force > 0 ? 1 : -1; g_gemm256_force = 0; return 0; }
+    if (force == 2 || force == -2) { g_splitk_enabled = force > 0; return 0; }
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
+    g_splitk_enabled = true;
     return 0;
 }
 extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>
@@ -267,9 +329,32 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
         return 0;
     }
-    const int grid = (d->N / BN) * ((d->M + BM - 1) / BM) * d->batch;
-    hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    int grid = (d->N / BN) * ((d->M + BM - 1) / BM) * d->batch;
+    // skinny problems (the 128-row text stream, the prompt encoders): < 128 workgroups, each a chain of K / 64 dependent
+    // memory latencies.  With scratch from the caller the K range is split so that ~256 workgroups run chains of >= 4
+    // K-tiles; a second launch sums the parts in split order and applies the epilogue.
+    const int nk = d->K / BK;
+    if (d->workspace && grid < 128 && nk >= 8 && g_splitk_enabled) {
+        int ks = (256 + grid - 1) / grid;
+        ks = ks < nk / 4 ? ks : nk / 4;
+        const long long per_split = (long long)d->batch * d->M * d->N * 4;
+        if (per_split * ks > d->workspace_bytes) ks = (int)(d->workspace_bytes / per_split);
+        if (ks > 1) {
+            a.ksplit = ks;
+            a.part = (float*)d->workspace;
+            grid *= ks;
+        }
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(gemm_kernel<false>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+    if (a.ksplit > 1) {
+        const long long total = (long long)d->batch * d->M * (d->N / 8);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(hipGetErrorString(e));
     return 0;

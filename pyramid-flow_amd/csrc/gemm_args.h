@@ -34,6 +34,8 @@ struct Args {
     int gelu_from, flags, n_valid;
     float out_scale;
     int group_m;             // M-tiles per L2 super-tile of the 256-row kernels (tile order; 0 = default)
+    int ksplit;              // 128 x 128 kernel: workgroups per output tile along K (0 / 1 = none); > 1 writes raw fp32
+    float* part;             //   partial sums part[((s * batch + b) * M + m) * N + n] instead of running the epilogue
     ConvGeom cg; OutMap om;
 };
 

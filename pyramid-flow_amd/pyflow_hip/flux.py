@@ -418,6 +418,9 @@ class FluxEngine(DeviceModuleAPI):
         # The text stream of a double block (rows [0, Lt): 6 small GEMMs, 2 workgroup waves on 256 CUs) is independent
         # of the image stream between the two joins around the attention: it runs on a side HIP stream and fills CUs
         # the image GEMMs' tails leave idle.  Rows / buffer regions of the two streams are disjoint.
+        # scratch of the text stream's GEMMs (128 rows per prompt: their K range is split, pf_gemm_desc.workspace); the
+        # image stream's skinny launches (small early units) run on the other stream and get their own
+        ws_txt = self._buf("splitk_txt", 8 << 20, torch.float32) if dbl else None
         main = torch.cuda.current_stream()
         side = self._side_stream() if (self.overlap_text and dbl) else None
         rec = ops.RECORDER                # recording a launch list: stream switches / joins become list entries
@@ -453,7 +456,7 @@ class FluxEngine(DeviceModuleAPI):
                 else:
                     ln(Lt, 0, mb + 6 * d, mb + 7 * d)
                 ops.gemm(xn, blk["kvq_txt"][0], big, Lt, (2 if tail else 3) * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1],
-                         batch=B, strideA=Ld, strideC=L3)
+                         batch=B, strideA=Ld, strideC=L3, workspace=ws_txt)
             ln(L_img, Lt * d, mb + 0, mb + d)
             if tail:
                 ops.gemm(xn, blk["kvq_img"][0], big, L_img, 2 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
@@ -474,13 +477,13 @@ class FluxEngine(DeviceModuleAPI):
                 with on_side():
                     ops.gemm(big, blk["o_txt"][0], hidden, Lt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                              gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
-                             flags=GEMM_GATE_RES, a_off=2 * d)
+                             flags=GEMM_GATE_RES, a_off=2 * d, workspace=ws_txt)
                     ln(Lt, 0, mb + 9 * d, mb + 10 * d)
                     ops.gemm(xn, blk["ff1_txt"][0], big, Lt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
-                             strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
+                             strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
                     ops.gemm(big, blk["ff2_txt"][0], hidden, Lt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
                              res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                             gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
+                             gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base, workspace=ws_txt)
             ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=r0 * 3 * d + 2 * d, c_off=r0 * d, r_off=r0 * d)

@@ -21,7 +21,8 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldw", C.c_int),
                 ("ldc", C.c_int), ("ldr", C.c_int),
                 ("strideA", C.c_longlong), ("strideC", C.c_longlong), ("strideR", C.c_longlong),
-                ("gate_stride", C.c_int), ("batch", C.c_int), ("gelu_from", C.c_int), ("flags", C.c_int)]
+                ("gate_stride", C.c_int), ("batch", C.c_int), ("gelu_from", C.c_int), ("flags", C.c_int),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
 
 
 class ConvDesc(C.Structure):

@@ -46,8 +46,9 @@ RECORDER = None      # a cmdlist.CommandList while a launch list is being record
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
-         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0):
-    """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res."""
+         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None):
+    """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res.  workspace: fp32 scratch tensor that lets
+    a skinny problem split its K range (pf_gemm_desc.workspace); must not be shared by overlapping launches."""
     lib = L.load()
     esz_c = 4 if (flags & GEMM_OUT_F32) else 2
     d = GemmDesc()
@@ -60,6 +61,8 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr = M, N, K, lda, ldw, ldc, ldr
     d.strideA, d.strideC, d.strideR = strideA, strideC, strideR
     d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     rec = RECORDER
     if rec is not None:
         check(lib.pf_cmdlist_gemm(rec.h, C.byref(d), C.c_int(rec.slot)))

@@ -60,6 +60,19 @@ def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_scratch(device):
+    """fp32 scratch that lets the encoders' skinny GEMMs (M = 77..256 rows) split their K range (pf_gemm_desc.workspace);
+    one per device, shared by the encoders: their launches are all on the current stream, in order"""
+    key = str(device)
+    t = _SPLITK_WS.get(key)
+    if t is None:
+        t = _SPLITK_WS[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+    return t
+
+
 class T5EncoderHIP:
     """``T5EncoderModel(input_ids, attention_mask)[0]`` -> last_hidden_state [B, L, d_model] bf16."""
 
@@ -129,16 +142,17 @@ class T5EncoderHIP:
         att = torch.empty(rows, inner, dtype=torch.bfloat16, device=dev)
         ff = torch.empty(rows, 2 * dff, dtype=torch.bfloat16, device=dev)
         gl = torch.empty(rows, dff, dtype=torch.bfloat16, device=dev)
+        ws = _splitk_scratch(dev)
         ops.embed_rows(self.embed, ids, h, d, rows, self.vocab)
         for w in self.layers:
             ops.rmsnorm(h, n, w["ln1"], d, rows, eps=self.eps)
-            ops.gemm(n, w["wqkv"], qkv, rows, 3 * inner, d, d, d, 3 * inner)
+            ops.gemm(n, w["wqkv"], qkv, rows, 3 * inner, d, d, d, 3 * inner, workspace=ws)
             ops.attention_small(qkv, att, 0, inner, 2 * inner, 3 * inner, inner, B, self.H, L, 1.0, bias=bias, key_mask=km)
-            ops.gemm(att, w["wo"], h, rows, d, inner, inner, inner, d, res=h, ldr=d, flags=GEMM_GATE_RES)
+            ops.gemm(att, w["wo"], h, rows, d, inner, inner, inner, d, res=h, ldr=d, flags=GEMM_GATE_RES, workspace=ws)
             ops.rmsnorm(h, n, w["ln2"], d, rows, eps=self.eps)
-            ops.gemm(n, w["wi"], ff, rows, 2 * dff, d, d, d, 2 * dff, gelu_from=dff)
+            ops.gemm(n, w["wi"], ff, rows, 2 * dff, d, d, d, 2 * dff, gelu_from=dff, workspace=ws)
             ops.glu_mul(ff, gl, rows, dff)
-            ops.gemm(gl, w["wff"], h, rows, d, dff, dff, dff, d, res=h, ldr=d, flags=GEMM_GATE_RES)
+            ops.gemm(gl, w["wff"], h, rows, d, dff, dff, dff, d, res=h, ldr=d, flags=GEMM_GATE_RES, workspace=ws)
         ops.rmsnorm(h, n, self.ln_f, d, rows, eps=self.eps)
         return n.view(B, L, d)
 
@@ -227,15 +241,16 @@ class CLIPTextHIP:
         qkv = torch.empty(rows, 3 * d, dtype=torch.bfloat16, device=dev)
         att = torch.empty(rows, d, dtype=torch.bfloat16, device=dev)
         ff = torch.empty(rows, dff, dtype=torch.bfloat16, device=dev)
+        ws = _splitk_scratch(dev)
         ops.embed_rows(self.tok, ids, h, d, rows, self.vocab, pos=self.pos, Lseq=L)
         for w in self.layers:
             self._ln(h, n, w["ln1"], rows)
-            ops.gemm(n, w["wqkv"], qkv, rows, 3 * d, d, d, d, 3 * d, bias=w["bqkv"])
+            ops.gemm(n, w["wqkv"], qkv, rows, 3 * d, d, d, d, 3 * d, bias=w["bqkv"], workspace=ws)
             ops.attention_small(qkv, att, 0, d, 2 * d, 3 * d, d, B, self.H, L, 0.125, causal=True)
-            ops.gemm(att, w["wo"], h, rows, d, d, d, d, d, bias=w["bo"], res=h, ldr=d, flags=GEMM_GATE_RES)
+            ops.gemm(att, w["wo"], h, rows, d, d, d, d, d, bias=w["bo"], res=h, ldr=d, flags=GEMM_GATE_RES, workspace=ws)
             self._ln(h, n, w["ln2"], rows)
-            ops.gemm(n, w["w1"], ff, rows, dff, d, d, d, dff, bias=w["b1"], gelu_from=0, flags=self.act_flag)
-            ops.gemm(ff, w["w2"], h, rows, d, dff, dff, dff, d, bias=w["b2"], res=h, ldr=d, flags=GEMM_GATE_RES)
+            ops.gemm(n, w["w1"], ff, rows, dff, d, d, d, dff, bias=w["b1"], gelu_from=0, flags=self.act_flag, workspace=ws)
+            ops.gemm(ff, w["w2"], h, rows, d, dff, dff, dff, d, bias=w["b2"], res=h, ldr=d, flags=GEMM_GATE_RES, workspace=ws)
         self._ln(h, n, self.ln_f, rows)
         pooled = torch.empty(B, d, dtype=torch.bfloat16, device=dev)
         for b, e in enumerate(self.eos_positions(input_ids)):

@@ -276,3 +276,55 @@ def test_bf16_trajectory_rounding_points_bit_exact():
         if mul != 1.0:
             ref = ref * mul
         assert torch.equal(pooled.cpu(), ref.float()), mul
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,B,N,K,flavour", [
+    (128, 2, 5760, 1920, "bias"), (128, 2, 1920, 7680, "gate_res"), (128, 2, 7680, 1920, "gelu"), (77, 1, 1280, 5120, "gate_res"),
+    (128, 1, 20480, 4096, "gelu_from"), (256, 1, 4096, 10240, "gate_res"), (100, 2, 1536, 1536, "f32"), (128, 2, 1920, 1920, "quick"),
+])
+def test_skinny_gemm_split_k(M, B, N, K, flavour):
+    """split-K path of the 128x128 kernel (workspace given, < 128 tiles): every epilogue flavour against torch fp32 and
+    against the same launch without the workspace"""
+    import torch.nn.functional as F
+    from pyflow_hip import ops
+    from util import rel_l2
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(B, M, K, generator=g)).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(B, M, N, generator=g).to(torch.bfloat16).cuda()
+    gate = torch.randn(B, N, generator=g).cuda()
+    ws = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    kw = dict(bias=bias, batch=B, strideA=M * K, strideC=M * N)
+    ref = A.float() @ W.float().T + bias
+    if flavour == "gate_res":
+        kw.update(res=res, gate=gate, ldr=N, strideR=M * N, gate_stride=N, flags=ops.GEMM_GATE_RES)
+        ref = res.float() + gate[:, None, :] * ref
+    elif flavour == "gelu":
+        kw.update(gelu_from=0)
+        ref = F.gelu(ref, approximate="tanh")
+    elif flavour == "gelu_from":
+        kw.update(gelu_from=N // 2)
+        ref[..., N // 2:] = F.gelu(ref[..., N // 2:], approximate="tanh")
+    elif flavour == "quick":
+        kw.update(gelu_from=0, flags=ops.GEMM_ACT_QUICK_GELU)
+        ref = ref * torch.sigmoid(1.702 * ref)
+    f32 = flavour == "f32"
+    if f32:
+        kw.update(flags=ops.GEMM_OUT_F32)
+    outs = []
+    for w_ in (ws, None):
+        out = torch.zeros(B, M + 2, N, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+        ops.gemm(A, W, out, M, N, K, K, K, N, **dict(kw, strideC=(M + 2) * N), workspace=w_)
+        outs.append(out)
+    split, plain = outs
+    assert split[:, M:].abs().max() == 0
+    assert rel_l2(split[:, :M].float(), ref) < 5e-3
+    assert rel_l2(split[:, :M].float(), plain[:, :M].float()) < 3e-3
+    # the scratch really was used (a split happened): its head holds partial sums, not garbage from torch.empty
+    ops.gemm_set_policy(-2)
+    out2 = torch.zeros_like(split)
+    ops.gemm(A, W, out2, M, N, K, K, K, N, **dict(kw, strideC=(M + 2) * N), workspace=ws)
+    ops.gemm_set_policy(2)
+    assert torch.equal(out2, plain)
