@@ -80,6 +80,9 @@ class FluxEngineSP(FluxEngine):
         obuf = self._buf("sp_obuf", L * B * max(mh, 1) * 64, bf)
         recv2 = self._buf("sp_recv2", B * nloc * d, bf)
         vT = self._buf("vT", B * max(mh, 1) * 64 * Lp, bf)
+        # scratch of the text rows' skinny GEMMs: same K split as the single-process engine (one 128-row tile per prompt
+        # either way), hence the same fp32 summation order and bit-identical text rows
+        ws_txt = self._buf("splitk_txt", 8 << 20, torch.float32)
         tok = self._buf("tok", B * L_img * w.in_ch, bf)
         Ld, L3, L4, L7 = nloc * d, nloc * 3 * d, nloc * 4 * d, nloc * 7 * d
         mlp_base = B * L3
@@ -138,7 +141,7 @@ class FluxEngineSP(FluxEngine):
                          strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d)
             if n_txt:
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
-                         strideA=Ld, strideC=L3)
+                         strideA=Ld, strideC=L3, workspace=ws_txt)
             norms = (blk["norm_q"], blk["norm_k"], blk["norm_added_q"], blk["norm_added_k"])
             attend(3 * d)
             self._exchange_out(lay, obuf, B, recv2, big, 3 * d, 0)          # attention rows -> big[..., 0:d]
@@ -149,7 +152,7 @@ class FluxEngineSP(FluxEngine):
             if n_txt and not pre_only:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES)
+                         gate_stride=nm, flags=GEMM_GATE_RES, workspace=ws_txt)
             ln(n_img, n_txt * d, mb + 3 * d, mb + 4 * d)
             if not pre_only:
                 ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
@@ -162,10 +165,10 @@ class FluxEngineSP(FluxEngine):
                          r_off=n_txt * d)
             if n_txt and not pre_only:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
-                         strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base)
+                         strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
                 ops.gemm(big, blk["ff2_txt"][0], hidden, n_txt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
                          res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base, workspace=ws_txt)
 
         for blk in w.sgl:
             mb = blk["mod"]
