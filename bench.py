@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--tiny-model", action="store_true", help="tiny random model (plumbing check, not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-period", type=int, default=7)
+    ap.add_argument("--no-overlap-text", action="store_true",
+                    help="run the double blocks' text stream on the compute stream instead of the side stream (A/B switch)")
     ap.add_argument("--launch-mode", default="graph", choices=["eager", "list", "graph"],
                     help="how the DiT's launches reach the device (pyflow_hip/cmdlist.py); default = the engine's default")
     ap.add_argument("--parallelism", default="sp", choices=["sp", "replicas"],
@@ -299,6 +301,8 @@ def main():
         image = torch.randn(3, H, W, generator=torch.Generator().manual_seed(77)).clamp(-1, 1)
         if hasattr(pipe.dit, "launch_mode"):
             pipe.dit.launch_mode = args.launch_mode
+        if args.no_overlap_text:
+            pipe.dit.overlap_text = False
         sp = SampledProfiler(pipe, args.profile_period)
 
         def one_video(seed):
