@@ -1,0 +1,615 @@
+// LAB COPY (not built, not shipped): gemm8p with K ROTATION -- with 256 KiB of caller scratch per workgroup, each workgroup
+// starts its first tile at K-tile h, parks the raw fp32 sums at the end of K, walks its other tiles normally and finishes
+// the first tile ([0, h) on top of the parked sums, which return through LDS in that tile's epilogue), so that tile
+// boundaries fall at h + k * nk instead of k * nk: de-phased store bursts without idle time.  Correct (16 parity cases,
+// all flavours), no spills -- and no gain: with h spread over the workgroups of an XCD the long-K residual GEMMs lose
+// 10-27 % (the workgroups of an XCD no longer read the same K slices at the same time: the L2 sharing of operand panels
+// is gone) and the K = 1920 GEMMs move -2.5 ... +1.7 %; with one h per XCD everything stays within +-2 %
+// (profiles/r02_gemm8p_pipelined_epilogue_ab.log, section (e)).  Kept for the record.
+// bf16 MFMA GEMM, persistent 256 x 256 block tile, v_mfma_f32_16x16x32_bf16, four ping-pong phases per K-tile.
+//
+// Same contract as gemm.hip / gemm256.hip (C = epi(A . W^T), optional implicit-GEMM conv addressing).  Serves the
+// large DiT projections (flux_block.py:756-758, 816-835, 868-872, 914-942) and the wide VAE CausalConv3d layers
+// (modeling_causal_conv.py:116-146).  What differs from gemm256.hip, and why:
+//   * ONE persistent workgroup per CU walks a list of output tiles; the operand stream (LDS-DMA, 1 KiB pieces) is a
+//     single pipeline that runs five load slots (1.25 K-tiles) ahead of the MFMAs and CROSSES tile boundaries: while a
+//     tile's epilogue stores drain, the first K-tile of the next tile is already in LDS.  At K = 1920 (30 K-tiles) the
+//     un-overlapped prologue + epilogue of gemm256.hip cost 10-15 % of a tile.
+//   * The epilogue never touches LDS: the MFMAs compute C^T tiles (operands swapped), so a lane owns 4 consecutive
+//     columns of one row per accumulator; the W rows are permuted on their way into LDS (the DMA source address is per
+//     lane) such that a lane's two accumulators of a column half are 8 CONSECUTIVE columns -> bias / GELU / gate*x+res
+//     and 16-byte stores straight from registers, no barrier, no staging strips.
+//   * 16x16x32 MFMAs on a 128 x 64 wave tile (2 x 4 waves): a K-tile is four phases of 16 MFMAs (one 64 x 32 quadrant
+//     x K = 64); the load slots of a K-tile read 12 / 4 / 8 / 0 fragments (A sub 0 + B sub 0, B sub 1, A sub 1, -: one
+//     A fragment set and both B sets stay in registers) and EVERY load slot issues ONE 16-KiB unit of the operand
+//     stream (2 pieces per wave), so the DMA instructions are spread evenly between the MFMA slots.
+//   * Two wave groups (the M halves) run one barrier apart: while one group issues its 16 MFMAs the other reads
+//     fragments and issues DMA (two barriers per phase).  One counted s_waitcnt vmcnt(8) per load slot: four units
+//     stay in flight across the barriers.  Invariant: at the end of load slot g (before its barrier) a wave's pieces
+//     of all units <= g+2 have landed; slot g reads units <= g+1; unit j+8 (same LDS region as unit j) is issued in
+//     slot j+2, two slots after the last read of unit j.
+// LDS: 2 K-tile buffers x (A 256 x 64 + W 256 x 64) bf16 = 128 KiB, XOR-swizzled like gemm256.hip (swizzle on the DMA
+// source address and on the ds_read_b128 address).
+#include "common.h"
+#include "pyflow_hip.h"
+#include "gemm_args.h"
+
+using namespace pfgemm;
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 32 KiB per operand per K-tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;    // 64 KiB
+constexpr int SMEM = 2 * BUF_BYTES;          // 128 KiB
+constexpr int GROUP_M = 4;
+
+#define PF_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PF_BAR()                          \
+    do {                                  \
+        PF_FENCE();                       \
+        __builtin_amdgcn_s_barrier();     \
+        PF_FENCE();                       \
+    } while (0)
+
+struct TileCoord { int b, m0, n0; };
+
+PF_DEVICE TileCoord tile_coord(const Args& p, int t, int tiles_m, int tiles_n) {
+    const int TM = tiles_m * p.batch;
+    const int GM = p.group_m > 0 ? p.group_m : GROUP_M;
+    const int group_sz = GM * tiles_n;
+    const int grp = t / group_sz;
+    const int first_m = grp * GM;
+    const int gm = min(TM - first_m, GM);
+    const int r_in = t - grp * group_sz;
+    const int tn = r_in / gm;
+    const int tmm = first_m + (r_in - tn * gm);
+    const int b = tmm / tiles_m, tm = tmm - b * tiles_m;
+    return TileCoord{b, tm * BM, tn * BN};
+}
+
+template <bool CONV, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;          // wave tile: rows wm*128 .. +128, columns wn*64 .. +64
+
+    // ---- this workgroup's tile list: XCD x (= blockIdx % 8) owns a contiguous chunk of the logical tile order, its
+    //      workgroups take the chunk's tiles round-robin, so the tiles in flight on one XCD are neighbours (shared
+    //      operand panels in that XCD's L2).
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int T = tiles_m * p.batch * tiles_n;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nslot = (nwg - xcd + 7) >> 3;
+    const int cq = T >> 3, cr = T & 7;
+    const int cs = xcd * cq + min(xcd, cr);
+    const int clen = cq + (xcd < cr ? 1 : 0);
+    const int n_my = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;
+    if (n_my == 0) return;
+    const int nk = p.K / BK;
+    const int U = 4 * nk * n_my;                    // 16-KiB units of the operand stream (A0, B0, B1, A1 per K-tile)
+
+    // ---- K rotation (needs scratch from the caller, p.part).  All 256 workgroups walk tiles of equal length, so they
+    //      reach their tile boundaries -- drain, conversions, 128 KiB of stores each -- at the same moments; measured, a
+    //      launch whose workgroups START up to one tile period apart takes no longer than an aligned one
+    //      (profiles/r02_gemm8p_pipelined_epilogue_ab.log), i.e. de-phased boundaries are worth 2-4 us of the ~10 us
+    //      each costs.  The phases come for free by splitting ONE tile per workgroup: it starts its first tile at
+    //      K-tile h (h spread evenly over the workgroups of an XCD and offset between XCDs), parks the raw fp32
+    //      accumulators in its private 256 KiB of scratch when it reaches the end of K, walks its other tiles normally
+    //      and finally runs K-tiles [0, h) of the first tile on top of the parked sums.  Same work, same operand
+    //      stream, boundaries at h + k * nk instead of k * nk.  Segments: sg = 0 .. NS-1.
+    const int rot_h = (!CONV && p.part && n_my >= 2 && nk >= 8) ? (xcd * nk) >> 3 : 0;
+    const int NS = n_my + (rot_h > 0 ? 1 : 0);
+    auto seg_tile = [&](int sg) { return (rot_h > 0 && sg == n_my) ? 0 : sg; };
+    auto seg_begin = [&](int sg) { return (rot_h > 0 && sg == 0) ? rot_h : 0; };
+    auto seg_end = [&](int sg) { return (rot_h > 0 && sg == n_my) ? rot_h : nk; };
+
+    // ---- DMA geometry.  A unit = 16 pieces of 8 LDS rows; wave w owns pieces 2w, 2w+1 of every unit.
+    //   A sub s (s = 0,1): LDS rows wm'*128 + s*64 + [0,64) for wm' = 0,1   (natural row order)
+    //   B sub s:           LDS rows wn'*64 + s*32 + [0,32) for wn' = 0..3;  LDS row wn'*64 + 16 j + i holds W row
+    //                      n0 + wn'*64 + 32 (j>>1) + 8 (i>>2) + 4 (j&1) + (i&3)      (the epilogue permutation)
+    // lane -> row-in-piece lane>>3, LDS chunk lane&7 holds source chunk (lane&7) ^ ((row>>1)&7).
+    // `ln` = lane, laundered through an empty asm where the per-tile set-up uses it: otherwise the compiler hoists a
+    // dozen loop-invariant lane-geometry values out of the main loop and keeps them in registers the loop needs
+    auto a_lds_row = [&](int ln, int s_, int e) { const int idx = 2 * wid + e; return (idx >> 3) * 128 + s_ * 64 + (idx & 7) * 8 + (ln >> 3); };
+    auto b_lds_row = [&](int ln, int s_, int e) { const int idx = 2 * wid + e; return (idx >> 2) * 64 + s_ * 32 + (idx & 3) * 8 + (ln >> 3); };
+    auto b_w_row = [&](int ln, int s_, int e) {          // W row (relative to n0) stored in LDS row b_lds_row(s_, e)
+        const int idx = 2 * wid + e, within = idx & 3;
+        const int i = (within & 1) * 8 + (ln >> 3);
+        return (idx >> 2) * 64 + 32 * s_ + 8 * (i >> 2) + 4 * (within >> 1) + (i & 3);
+    };
+    // wave-uniform LDS destinations (piece bases) inside a buffer
+    auto a_dst = [&](int s_, int e) { const int idx = 2 * wid + e; return ((idx >> 3) * 128 + s_ * 64 + (idx & 7) * 8) * 128; };
+    auto b_dst = [&](int s_, int e) { const int idx = 2 * wid + e; return TILE_BYTES + ((idx >> 2) * 64 + s_ * 32 + (idx & 3) * 8) * 128; };
+
+    // ---- issue-side state: (tile, K-tile) of the unit group being issued, per-lane byte offsets relative to the
+    //      tile's scalar base pointers
+    int is_seg = 0, is_kt = 0, is_kt_end = nk;
+    const char* is_abase = nullptr;                 // A + batch/tile offset (bytes), wave-uniform
+    const char* is_wbase = nullptr;
+    unsigned a_off[2][2], w_off[2][2];
+    // conv tap walk of the issue stream (CONV only)
+    int is_c0 = 0, is_dw = 0, is_dh = 0, is_dt = 0;
+
+    auto setup_issue_tile = [&](int seq, int kt0) {
+        const TileCoord tc = tile_coord(p, cs + slot + seq * nslot, tiles_m, tiles_n);
+        const bf16_t* A = p.A + (long long)tc.b * p.sA;
+        long long base_el;                          // element offset of the tile's first row
+        if (CONV) {
+            const int hw = p.cg.H * p.cg.W;
+            const int tt = tc.m0 / hw, rem = tc.m0 - tt * hw;
+            const int hh = rem / p.cg.W, ww = rem - hh * p.cg.W;
+            base_el = p.cg.base_off + (((long long)tt * p.cg.st * p.cg.Hp + hh * p.cg.sh) * p.cg.Wp + ww * p.cg.sw) * p.cg.Cin;
+        } else {
+            base_el = (long long)tc.m0 * p.lda;
+        }
+        is_abase = (const char*)(A + base_el);
+        is_wbase = (const char*)(p.W + (long long)tc.n0 * p.ldw);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ra = a_lds_row(ln, s, e), rb = b_lds_row(ln, s, e);
+                int m = tc.m0 + ra;
+                m = m < p.M ? m : p.M - 1;
+                long long el;
+                if (CONV) {
+                    const int hw = p.cg.H * p.cg.W;
+                    const int tt = m / hw, rem = m - tt * hw;
+                    const int hh = rem / p.cg.W, ww = rem - hh * p.cg.W;
+                    el = p.cg.base_off + (((long long)tt * p.cg.st * p.cg.Hp + hh * p.cg.sh) * p.cg.Wp + ww * p.cg.sw) * p.cg.Cin;
+                } else {
+                    el = (long long)m * p.lda;
+                }
+                a_off[s][e] = (unsigned)((el - base_el) * 2 + (((ln & 7) ^ ((ra >> 1) & 7)) << 4));
+                int n = tc.n0 + b_w_row(ln, s, e);
+                n = n < p.N ? n : p.N - 1;
+                w_off[s][e] = (unsigned)((long long)(n - tc.n0) * p.ldw * 2 + (((ln & 7) ^ ((rb >> 1) & 7)) << 4));
+            }
+        is_kt = kt0;                                // (a start inside K only happens without CONV: rot_h)
+        is_c0 = is_dw = is_dh = is_dt = 0;
+    };
+
+    // byte offset of the issue stream's current K-tile inside a row of A
+    auto a_koff = [&]() -> long long {
+        if (CONV) return ((((long long)is_dt * p.cg.Hp + is_dh) * p.cg.Wp + is_dw) * p.cg.Cin + is_c0) * 2;
+        return (long long)is_kt * (BK * 2);
+    };
+
+    // issue unit j of the stream (kind j&3: 0 = A sub 0, 1 = B sub 0, 2 = B sub 1, 3 = A sub 1) into buffer (j>>2)&1
+    auto issue_unit = [&](int j) {
+        const int kind = j & 3;
+        char* buf = smem + ((j >> 2) & 1) * BUF_BYTES;
+        if (kind == 0 || kind == 3) {
+            const int s = kind == 0 ? 0 : 1;
+            const char* src = is_abase + a_koff();
+#pragma unroll
+            for (int e = 0; e < 2; ++e) glds16(src + a_off[s][e], buf + a_dst(s, e));
+        } else {
+            const int s = kind - 1;
+            const char* src = is_wbase + (long long)is_kt * (BK * 2);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) glds16(src + w_off[s][e], buf + b_dst(s, e));
+        }
+        if (kind == 3) {                            // K-tile complete: advance the issue stream
+            ++is_kt;
+            if (CONV) {
+                is_c0 += BK;
+                if (is_c0 == p.cg.Cin) {
+                    is_c0 = 0;
+                    if (++is_dw == p.cg.kw) { is_dw = 0; if (++is_dh == p.cg.kh) { is_dh = 0; ++is_dt; } }
+                }
+            }
+            if (is_kt == is_kt_end) {
+                ++is_seg;
+                if (is_seg < NS) {
+                    setup_issue_tile(seg_tile(is_seg), seg_begin(is_seg));
+                    is_kt_end = seg_end(is_seg);
+                }
+            }
+        }
+    };
+
+    // ---- fragment reads.  16x16x32 operand: lane -> row (lane&15) of the 16-row fragment, k chunk 4 kk + (lane>>4).
+    const int frow = lane & 15, fq = lane >> 4, fswz = (lane >> 1) & 7;
+    const int a_rd = (wm * 128 + frow) * 128;                       // + s*64*128 + f*16*128 + chunk
+    const int b_rd = TILE_BYTES + (wn * 64 + frow) * 128;           // + s*32*128 + jj*16*128 + chunk
+    int ch[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) ch[kk] = ((4 * kk + fq) ^ fswz) << 4;
+
+    bf16x8_t fa[4][2];           // [m-fragment][kk] of the CURRENT A sub-tile (sub 0 in phases 0-1, sub 1 in 2-3)
+    bf16x8_t fb[2][2][2];        // [sub][n-fragment][kk]   W rows (the MFMA "A" operand)
+    f32x4v acc[8][4];            // [m-fragment 0..7][n-fragment 0..3]: C^T tile, lane: row lane&15, cols 4 fq + r
+    // The accumulators of a tile START at the bias of their columns (zero without a bias): the epilogue has no bias
+    // loads to wait for and no adds; the next tile's bias is requested at the top of the epilogue and lands under it.
+    f32x4_t nb0, nb1, nb2, nb3;  // bias of the wave's columns in accumulator order (n-fragment 0..3); named scalars:
+                                 // an array of vectors written under a condition ends up in scratch memory
+    // (the residual flavour has no registers to spare for this: it starts from zero and adds the bias in its epilogue)
+    constexpr bool FOLD_BIAS = (EPI & 1) == 0;
+    auto load_bias = [&](int seq) {
+        const TileCoord tc = tile_coord(p, cs + slot + seq * nslot, tiles_m, tiles_n);
+        const f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        nb0 = nb1 = nb2 = nb3 = z;
+        if (FOLD_BIAS && p.bias) {
+            const int c0 = tc.n0 + wn * 64 + 8 * fq, c1 = c0 + 32;
+            const float* b0 = p.bias + (c0 < p.n_valid ? c0 : 0);
+            const float* b1 = p.bias + (c1 < p.n_valid ? c1 : 0);
+            nb0 = *(const f32x4_t*)b0;
+            nb1 = *(const f32x4_t*)(b0 + 4);
+            nb2 = *(const f32x4_t*)b1;
+            nb3 = *(const f32x4_t*)(b1 + 4);
+        }
+    };
+    auto acc_from_bias = [&]() {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            acc[f][0] = (f32x4v){nb0[0], nb0[1], nb0[2], nb0[3]};
+            acc[f][1] = (f32x4v){nb1[0], nb1[1], nb1[2], nb1[3]};
+            acc[f][2] = (f32x4v){nb2[0], nb2[1], nb2[2], nb2[3]};
+            acc[f][3] = (f32x4v){nb3[0], nb3[1], nb3[2], nb3[3]};
+        }
+    };
+    load_bias(0);
+    acc_from_bias();
+
+    auto read_a = [&](int s, int bufsel) {
+        const char* base = smem + bufsel * BUF_BYTES + a_rd + s * (64 * 128);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fa[f][kk] = *(const bf16x8_t*)(base + f * (16 * 128) + ch[kk]);
+    };
+    auto read_b = [&](int s, int bufsel) {
+        const char* base = smem + bufsel * BUF_BYTES + b_rd + s * (32 * 128);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) fb[s][jj][kk] = *(const bf16x8_t*)(base + jj * (16 * 128) + ch[kk]);
+    };
+    auto mfma_quadrant = [&](int sa, int sb) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[sa * 4 + f][sb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        fb[sb][jj][kk], fa[f][kk], acc[sa * 4 + f][sb * 2 + jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- K rotation: park / restore the raw accumulators (lane-linear 16-byte pieces in the workgroup's scratch)
+    // (the lane term is laundered inside each use: otherwise the compiler precomputes the 32 piece addresses outside the
+    //  main loop and keeps 64 registers alive for them)
+    // ---- epilogue of the compute tile, straight from the accumulators.  The flavour (residual, fp32 output, GELU) is a
+    //      template parameter: a branch-free epilogue is a few hundred instructions; the all-runtime form was ~60 KB of
+    //      code that missed the instruction cache once per tile (measured: 13 % of a K = 1920 tile).
+    //      Order: request bias / gate / the residual pieces, drain the vector-memory queue ONCE (this also retires
+    //      every DMA issued so far, see the main loop), then fp32 math and one 16-byte store per (row fragment, half).
+    constexpr bool E_RES = (EPI & 1) != 0, E_F32 = (EPI & 2) != 0, E_ACT = (EPI & 4) != 0;
+    // mode: 0 a whole tile | 1 end of K of the rotated first tile: park the raw sums, no output | 2 the rest of that tile:
+    //       output = epi(accumulators + parked sums).  nxt: what the accumulators restart from -- 0 nothing follows, 1 the
+    //       bias of tile `nxt_seq`, 2 zero (the parked sums, which hold the bias, are added in that tile's epilogue).
+    auto epilogue = [&](int seq, int mode, int nxt, int nxt_seq) {
+        const TileCoord tc = tile_coord(p, cs + slot + seq * nslot, tiles_m, tiles_n);
+        const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
+        const bool mapped = CONV && p.om.mode == 1;
+        // output element offset of (row m, column n); false = nothing to store for this row
+        auto out_off = [&](int m, int n, long long& coff) -> bool {
+            if (mapped) {
+                const int hw = p.om.H * p.om.W;
+                const int tt = m / hw, rem = m - tt * hw;
+                const int hh = rem / p.om.W, ww = rem - hh * p.om.W;
+                const int gg = n / p.om.Cg, cc = n - gg * p.om.Cg;
+                const int shw = p.om.sh * p.om.sw;
+                const int pt = gg / shw, g2 = gg - pt * shw;
+                const int ph = g2 / p.om.sw, pw = g2 - ph * p.om.sw;
+                const int tf = tt * p.om.st + pt + p.om.t_shift;
+                coff = p.om.base_off +
+                       (((long long)(tf < 0 ? 0 : tf) * p.om.Hop + (hh * p.om.sh + ph)) * p.om.Wop + (ww * p.om.sw + pw)) *
+                           p.om.Cout_pitch + cc;
+                return tf >= 0;
+            }
+            coff = (long long)tc.b * p.sC + (long long)m * p.ldc + n;
+            return true;
+        };
+        const bf16_t* res_row = E_RES ? p.res + (long long)tc.b * p.sR + (long long)(wave_m0 + frow) * p.ldr : nullptr;
+        char* const c_row = (char*)p.C + ((long long)tc.b * p.sC + (long long)(wave_m0 + frow) * p.ldc) * (E_F32 ? 4 : 2);
+        int ncol[2];
+        bool ncol_ok[2];
+        f32x4_t gate4[2][2];
+        f32x4_t rb0, rb1;                                       // residual flavour: bias of the current column half
+        if (FOLD_BIAS && nxt == 1) load_bias(nxt_seq);         // consumed after the stores are issued (acc_from_bias)
+        auto load_col_params = [&](int hsel) {
+            const int n_raw = wave_n0 + 32 * hsel + 8 * fq;
+            ncol_ok[hsel] = n_raw < p.n_valid;
+            const int n = ncol_ok[hsel] ? n_raw : 0;           // clamped: loads stay in bounds, stores are masked
+            ncol[hsel] = n;
+            if (E_RES) {
+                rb0 = rb1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    rb0 = *(const f32x4_t*)(p.bias + n);
+                    rb1 = *(const f32x4_t*)(p.bias + n + 4);
+                }
+                if (p.gate) {
+                    const float* gp = p.gate + (long long)tc.b * p.gate_stride + n;
+                    gate4[hsel][0] = *(const f32x4_t*)gp;
+                    gate4[hsel][1] = *(const f32x4_t*)(gp + 4);
+                } else {
+                    gate4[hsel][0] = gate4[hsel][1] = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+                }
+            }
+        };
+        if (!E_RES) {          // one wait for both halves; the residual flavour waits per half and loads them there
+            load_col_params(0);
+            load_col_params(1);
+        }
+        // mode 2: the parked sums come back through LDS (the operand stream has ended: this is the workgroup's last
+        // epilogue), one column half = 16 lane-linear 1-KiB pieces per wave at a time, so that they cost no registers.
+        // The barrier pairs group 0's arrival here with group 1's last in-loop barrier (after its last fragment reads).
+        int lnp = lane;
+        asm volatile("" : "+v"(lnp));
+        const char* const park_src = (const char*)p.part + ((long long)bid * 8 + wid) * 32768 + (unsigned)lnp * 16u;
+        char* const park_lds = smem + wid * 16384;
+        if (mode == 2) PF_BAR();
+        // vmcnt counts loads and stores in issue order: a load queued behind the tile's stores would wait for them, so
+        // every load of the epilogue is issued before the first store and the bf16 results are packed in registers
+        // (they take the place of the accumulators they were computed from) until both column halves are done.
+        u32x4_t outp[2][8];
+        // row fragments per batch: the residual flavour loads a column half's 8 residual pieces, waits once, converts them
+        // (two drains per tile; 4-fragment batches = four drains measured 0.5-2.5 % slower)
+        constexpr int FB = 8;
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel) {
+            if (E_RES) load_col_params(hsel);
+            const int n = ncol[hsel];
+            // wave-uniform (gelu_from is a multiple of 32, pf_gemm8p_supports): the column halves left of gelu_from skip
+            // the activation's VALU work instead of computing and discarding it
+            const bool do_act = E_ACT && (wave_n0 + 32 * hsel) >= p.gelu_from;
+#pragma unroll
+            for (int f0 = 0; f0 < 8; f0 += FB) {
+                u32x4_t rbuf[FB];
+                if (E_RES && mode != 1) {
+#pragma unroll
+                    for (int f = 0; f < FB; ++f) {
+                        const int m = wave_m0 + 16 * (f0 + f) + frow;
+                        if (mapped) {
+                            long long roff;
+                            out_off(m < p.M ? m : p.M - 1, n, roff);
+                            rbuf[f] = *(const u32x4_t*)(p.res + roff);
+                        } else {
+                            // one per-lane row pointer + a wave-uniform fragment stride: no per-fragment 64-bit
+                            // offsets kept alive across the epilogue; rows past M are not read at all
+                            rbuf[f] = (u32x4_t){0u, 0u, 0u, 0u};
+                            if (m < p.M) rbuf[f] = *(const u32x4_t*)(res_row + (long long)(16 * (f0 + f)) * p.ldr + n);
+                        }
+                    }
+                }
+                if (mode == 2) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)      // piece q of the half = accumulator (fragment q >> 1, column group 2 hsel + (q & 1))
+                        glds16(park_src + ((q >> 1) * 4 + 2 * hsel + (q & 1)) * 1024, park_lds + q * 1024);
+                }
+                if ((hsel == 0 && f0 == 0) || E_RES || mode == 2) {
+                    // drains the DMA queue (see the main loop) and, for the residual flavour, this batch's pieces
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PF_FENCE();
+                }
+#pragma unroll
+                for (int fi = 0; fi < FB; ++fi) {
+                    const int f = f0 + fi;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[f][2 * hsel][r];
+                        v[4 + r] = acc[f][2 * hsel + 1][r];
+                    }
+                    if (mode == 1) {
+                        // park the raw sums of the rotated first tile (piece = accumulator index, lane-linear 16 bytes)
+                        char* const pw = (char*)p.part + ((long long)bid * 8 + wid) * 32768 + (unsigned)lnp * 16u;
+                        *(f32x4_t*)(pw + (f * 4 + 2 * hsel) * 1024) = (f32x4_t){v[0], v[1], v[2], v[3]};
+                        *(f32x4_t*)(pw + (f * 4 + 2 * hsel + 1) * 1024) = (f32x4_t){v[4], v[5], v[6], v[7]};
+                        PF_FENCE();
+                        continue;
+                    }
+                    if (mode == 2) {
+                        const f32x4_t q0 = *(const f32x4_t*)(park_lds + (2 * f) * 1024 + lnp * 16);
+                        const f32x4_t q1 = *(const f32x4_t*)(park_lds + (2 * f + 1) * 1024 + lnp * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] += q0[r]; v[4 + r] += q1[r]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (!FOLD_BIAS) {
+                            v[r] += rb0[r];
+                            v[4 + r] += rb1[r];
+                        }
+                    }
+                    if (E_ACT) {
+                        if (do_act) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                        }
+                    }
+                    if (E_RES) {
+                        float rv[8];
+                        unpack8(rbuf[fi], rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = rv[e] + gate4[hsel][0][e] * v[e];
+                            v[4 + e] = rv[4 + e] + gate4[hsel][1][e] * v[4 + e];
+                        }
+                    }
+                    if (CONV) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+                    }
+                    if (E_F32) {
+                        const int m = wave_m0 + 16 * f + frow;
+                        if (m < p.M && ncol_ok[hsel]) {
+                            float* c = (float*)(c_row + ((long long)(16 * f) * p.ldc + n) * 4);
+                            *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
+                            *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+                        }
+                    } else {
+                        outp[hsel][f] = pack8(v);
+                    }
+                    PF_FENCE();                    // keep the scheduler from overlapping fragments (register pressure)
+                }
+            }
+        }
+        if (!E_F32 && mode != 1) {
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const int m = wave_m0 + 16 * f + frow;
+                    if (mapped) {
+                        long long coff;
+                        const bool ok = out_off(m < p.M ? m : p.M - 1, ncol[hsel], coff) && m < p.M && ncol_ok[hsel];
+                        if (ok) *(u32x4_t*)((bf16_t*)p.C + coff) = outp[hsel][f];
+                    } else if (m < p.M && ncol_ok[hsel]) {
+                        *(u32x4_t*)(c_row + ((long long)(16 * f) * p.ldc + ncol[hsel]) * 2) = outp[hsel][f];
+                    }
+                    PF_FENCE();
+                }
+        }
+        // the accumulators restart (from the next tile's bias) only now: re-initialising them while the packed results
+        // are still waiting for their stores would keep 128 + 64 registers alive at once
+        PF_FENCE();
+        if (nxt == 2) nb0 = nb1 = nb2 = nb3 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        acc_from_bias();
+    };
+
+    // ---- prologue: units 0..5; units 0 and 1 (A sub 0, B sub 0 of the first K-tile: what load slot 0 reads) must have
+    //      landed before the first barrier
+    setup_issue_tile(seg_tile(0), seg_begin(0));
+    is_kt_end = seg_end(0);
+    {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < U) issue_unit(j);
+        if (U >= 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PF_BAR();
+    if (wm == 1) PF_BAR();                 // group 1 runs one barrier behind group 0
+
+    // ---- main loop over the K-tiles of all tiles of this workgroup
+    // load slot g reads units <= g+1 and issues unit g+6; then: all units <= g+2 of this wave have landed.
+    int skip_wait = 0;                      // load slots after an epilogue whose wait is already covered
+    auto end_of_load_slot = [&](int g) {
+        if (g + 6 < U) {
+            issue_unit(g + 6);
+            if (skip_wait > 0) --skip_wait;
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PF_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PF_FENCE();
+    };
+
+    int c_seg = 0, c_kt = seg_begin(0), c_end = seg_end(0);
+    const int GK = nk * n_my;
+    for (int gk = 0; gk < GK; ++gk) {
+        const int bs = gk & 1;
+        const int g = 4 * gk;
+        // phase 0: A sub 0 + B sub 0 | quadrant (A0, B0)
+        read_b(0, bs);
+        PF_FENCE();
+        read_a(0, bs);
+        end_of_load_slot(g);
+        mfma_quadrant(0, 0);
+        PF_BAR();
+        // phase 1: B sub 1 | (A0, B1)
+        read_b(1, bs);
+        end_of_load_slot(g + 1);
+        mfma_quadrant(0, 1);
+        PF_BAR();
+        // phase 2: A sub 1 | (A1, B1)
+        read_a(1, bs);
+        end_of_load_slot(g + 2);
+        mfma_quadrant(1, 1);
+        PF_BAR();
+        // phase 3: no fragment reads (B sub 0 is still resident) | (A1, B0)
+        end_of_load_slot(g + 3);
+        mfma_quadrant(1, 0);
+        if (++c_kt == c_end) {
+            // every DMA issued so far has had >= one MFMA slot; draining here makes the waits of the next four load
+            // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
+            // epilogue out of the counted waits
+            PF_FENCE();
+            const int nsg = c_seg + 1;
+            epilogue(seg_tile(c_seg), rot_h > 0 ? (c_seg == 0 ? 1 : (c_seg == n_my ? 2 : 0)) : 0,
+                     nsg >= NS ? 0 : (rot_h > 0 && nsg == n_my ? 2 : 1), nsg);
+            PF_FENCE();
+            skip_wait = 4;
+            c_seg = nsg;
+            c_kt = seg_begin(nsg);
+            c_end = seg_end(nsg);
+        }
+        PF_BAR();
+    }
+    if (wm == 0) PF_BAR();                 // matches group 1's extra barrier
+}
+
+int g_num_cu = 0;
+bool g_rotate = true;
+
+template <bool CONV, int EPI>
+int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
+    Args a = a_in;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm8p_kernel<CONV, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    if (!g_num_cu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
+    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    // K rotation (see the kernel): 256 KiB of caller-provided scratch per workgroup
+    a.part = (!CONV && ws && g_rotate && ws_bytes >= (long long)grid * (256 << 10)) ? (float*)ws : nullptr;
+    hipLaunchKernelGGL((gemm8p_kernel<CONV, EPI>), dim3(grid), dim3(512), SMEM, stream, a);
+    return 0;
+}
+
+}  // namespace
+
+
+// Epilogue flavours that exist as instantiations: bias (+ out_scale for conv) always; ONE of {residual (+gate),
+// fp32 output, GELU-tanh from a column}.  Anything else (CLIP activations, combinations) is served by the older kernels.
+bool pf_gemm8p_supports(const Args& a, bool conv) {
+    if (a.flags & (PF_GEMM_ACT_QUICK_GELU | PF_GEMM_ACT_GELU_ERF)) return false;
+    const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
+    if ((int)res + (int)f32 + (int)act > 1) return false;
+    if (conv && (f32 || act || res)) return false;      // conv + shortcut add: the instantiation spills (kept on gemm256)
+    if (act && (a.gelu_from & 31)) return false;        // the activation is decided per 32-column half of a wave tile
+    return true;
+}
+
+int pf_gemm8p_launch(const Args& a_in, bool conv, hipStream_t stream, void* ws, long long ws_bytes) {
+    const Args& a = a_in;
+    const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
+    if (conv) return launch<true, 0>(a, stream, nullptr, 0);      // conv + shortcut add stays on gemm256 (pf_gemm8p_supports)
+    if (res) return launch<false, 1>(a, stream, ws, ws_bytes);
+    if (f32) return launch<false, 2>(a, stream, ws, ws_bytes);
+    if (act) return launch<false, 4>(a, stream, ws, ws_bytes);
+    return launch<false, 0>(a, stream, ws, ws_bytes);
+}
+
+void pf_gemm8p_set_rotate(bool on) { g_rotate = on; }
