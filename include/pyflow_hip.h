@@ -62,7 +62,8 @@ int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
  * else the 256 x BN ping-pong kernel (BN = 256 / 192 / 128) when it yields >= 192 tiles, else the 128 x 128 kernel;
  * -1 = always the 128 x 128 kernel; 128 / 192 / 256 = force the 256 x BN kernel whenever BN divides N;
  * 8 = force gemm8p whenever its epilogue flavour exists (bias + ONE of residual / fp32 output / GELU-tanh); -8 = never
- * gemm8p; -2 / 2 = never / again split K for skinny problems that bring a workspace.  Default 0. */
+ * gemm8p; -2 / 2 = never / again split K for skinny problems that bring a workspace; -3 / 3 = never / again
+ * the narrow-N conv kernel (3x3x3 convs with <= 8 output channels: the decoder's conv_out).  Default 0. */
 int pf_gemm_set_policy(int force);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =
  * gemm8p_kernel, BN > 0 = gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */

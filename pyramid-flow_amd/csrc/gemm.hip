@@ -266,12 +266,15 @@ int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force);
 int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, hipStream_t stream);
 int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream);      // gemm8p.hip: persistent 256 x 256 tiles
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
+bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
+int pf_conv_narrow_launch(const pf_conv_desc* d, hipStream_t stream);
 
 // tile-width policy of the 256-row ping-pong kernels: 0 (auto, default) | 128 | 192 | 256 (that width when it divides N) | -1 (never)
 static int g_gemm256_force = 0;
 static int gemm256_force() { return g_gemm256_force; }
 // gemm8p (persistent 256 x 256 tiles): 1 = whenever legal (policy 8), 0 = automatic, -1 = never (policy -8)
 static int g_gemm8p_mode = 0;
+static bool g_narrow_enabled = true;         // pf_gemm_set_policy(-3) / (3): never / again the narrow-N conv kernel
 static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
 static bool use_gemm8p(int M, int batch, int N, int K) {
@@ -287,8 +290,9 @@ static bool use_gemm8p(int M, int batch, int N, int K) {
 extern "C" int pf_gemm_set_policy(int force) {
     if (force == 8 || force == -8) { g_gemm8p_mode = force > 0 ? 1 : -1; g_gemm256_force = 0; return 0; }
     if (force == 2 || force == -2) { g_splitk_enabled = force > 0; return 0; }
+    if (force == 3 || force == -3) { g_narrow_enabled = force > 0; return 0; }
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 3, -3, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
@@ -367,6 +371,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     if (d->Cin % BK != 0) return set_err("pf_conv3d_bf16: Cin must be a multiple of 64 (pad channels)");
     if (d->N % BN != 0) return set_err("pf_conv3d_bf16: N must be a multiple of 128 (pad filters)");
     if (d->T <= 0 || d->H <= 0 || d->W_ <= 0) return set_err("pf_conv3d_bf16: empty problem");
+    if (g_narrow_enabled && pf_conv_narrow_supports(d)) return pf_conv_narrow_launch(d, stream);
     Args a{};
     a.A = (const bf16_t*)d->X; a.W = (const bf16_t*)d->W; a.C = d->Y;
     a.bias = d->bias; a.res = (const bf16_t*)d->res; a.gate = nullptr;

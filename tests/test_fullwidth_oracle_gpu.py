@@ -124,6 +124,21 @@ def test_vae_default_width_tile_decode_vs_oracle():
     assert out.shape == ref.shape and err < 2e-2
     out2 = vae.decode(z.cuda(), temporal_chunk=False).sample.float().cpu()
     assert rel_l2(out2, ref) < 2e-2
+    # conv_out (128 -> 3 channels) runs the narrow-N kernel (convnarrow.hip) by default: same result as the padded
+    # implicit GEMM up to the fp32 summation tree (a bf16 ulp here and there), chunked (T = 1 and 8) and un-chunked (T = 9)
+    from pyflow_hip import ops
+    ops.gemm_set_policy(-3)
+    try:
+        wide = vae.decode(z.cuda(), temporal_chunk=True, window_size=1).sample.float().cpu()
+        wide2 = vae.decode(z.cuda(), temporal_chunk=False).sample.float().cpu()
+    finally:
+        ops.gemm_set_policy(3)
+    assert rel_l2(wide, ref) < 2e-2
+    for a, b in ((out, wide), (out2, wide2)):
+        d = (a - b).abs()
+        assert d.max() <= 2 ** -6 * max(b.abs().max().item(), 1.0), d.max()
+        assert rel_l2(a, b) < 2e-3
+        assert not torch.equal(a, torch.zeros_like(a))
     # launch shapes of this decode: the full-resolution 128-filter convs (M = frames x 256 x 256 pixels) and the
     # 256/512-filter convs below them run the 256-row MFMA conv kernels
     assert _which(8 * 256 * 256, 1, 128, 27 * 128) != 0
