@@ -26,6 +26,10 @@ typedef struct ihipStream_t* pf_stream_t; /* == hipStream_t */
 
 const char* pf_last_error(void);
 int pf_version(void);
+/* sizeof() of the descriptor structs as this library was compiled: 0 pf_gemm_desc, 1 pf_conv_desc, 2 pf_attn_desc,
+ * 3 pf_attn_small_desc (-1 otherwise) -- lets a foreign-language binding (ctypes / cgo / JNI struct mirrors) verify its
+ * layout at load time instead of corrupting a launch. */
+int pf_struct_size(int which);
 
 /* ------------------------------------------------------------------ GEMM (nn.Linear) ------------
  * C[b] = epi( A[b] (M x K, row stride lda) . W^T (W is N x K, row stride ldw, nn.Linear layout) )

@@ -10,4 +10,13 @@ int pf_set_err(const char* m) {
 }
 
 extern "C" const char* pf_last_error(void) { return g_err; }
-extern "C" int pf_version(void) { return 1; }
+extern "C" int pf_version(void) { return 2; }
+extern "C" int pf_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(pf_gemm_desc);
+        case 1: return (int)sizeof(pf_conv_desc);
+        case 2: return (int)sizeof(pf_attn_desc);
+        case 3: return (int)sizeof(pf_attn_small_desc);
+        default: return -1;
+    }
+}

@@ -67,3 +67,13 @@ def test_launch_list_bookkeeping_without_a_device():
     assert lib.pf_cmdlist_join(h, C.c_int(0), C.c_int(0)) != 0
     assert lib.pf_cmdlist_clear(h) == 0 and lib.pf_cmdlist_size(h) == 0
     assert lib.pf_cmdlist_destroy(h) == 0
+
+
+def test_struct_mirrors_match_the_compiled_layout():
+    """the ctypes mirrors of the descriptor structs have the sizes the library was compiled with (also checked at load)"""
+    import ctypes as C
+    from pyflow_hip import lib as L
+    lib = L.load()
+    for which, cls in enumerate((L.GemmDesc, L.ConvDesc, L.AttnDesc, L.AttnSmallDesc)):
+        assert lib.pf_struct_size(C.c_int(which)) == C.sizeof(cls), cls.__name__
+    assert lib.pf_struct_size(C.c_int(99)) == -1
