@@ -1,3 +1,5 @@
 #!/bin/bash
+# the rebuilt library loads and runs on the GPU box: smoke() + C-API + launch-list tests
 mkdir -p gpurun_out
-timeout 400 python -m pytest tests/test_gemm256_gpu.py tests/test_hip_ops.py tests/test_flux_forward_gpu.py tests/test_vae_gpu.py -x -q 2>&1 | tail -3
+( timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1; timeout 300 python -m pytest tests/test_capi.py tests/test_cmdlist_gpu.py -q 2>&1 | tail -2 ) > gpurun_out/sanity.log
+cat gpurun_out/sanity.log
