@@ -279,3 +279,72 @@ def test_text_encoder_wrappers_vs_reference(ref):
         emb3, mask3, pooled3 = rs(prompts, torch.device("cpu"))
         assert torch.equal(emb3, exp_emb) and torch.equal(mask3, ti.attention_mask)
         assert torch.equal(pooled3, torch.cat([clp(ci.input_ids).text_embeds, cg(ci.input_ids).text_embeds], -1))
+
+
+def test_flux_oracle_at_released_width(ref):
+    """the oracle against the unmodified reference at the RELEASED miniFLUX width (d = 1920, 30 heads -- a head count
+    that is not a power of two), one double + one single block, history clips + padded text: the configuration the GPU
+    full-width tests (tests/test_fullwidth_oracle_gpu.py) compare the HIP kernels with"""
+    from oracle import ref_harness as rh
+    from oracle.flux_oracle import flux_forward
+    from pyflow_hip import synth
+    cfg = dict(synth.MINIFLUX, num_layers=1, num_single_layers=1)
+    m = rh.build_ref_dit(cfg, seed=77)
+    g = torch.Generator().manual_seed(9)
+    clips = [torch.randn(2, 16, 2, 6, 10, generator=g), torch.randn(2, 16, 1, 12, 20, generator=g),
+             torch.randn(2, 16, 1, 12, 20, generator=g)]
+    enc = torch.randn(2, 24, 4096, generator=g)
+    mask = torch.zeros(2, 24, dtype=torch.long)
+    mask[0, :7] = 1
+    mask[1, :19] = 1
+    pooled = torch.randn(2, 768, generator=g)
+    t = torch.tensor([431.5, 431.5])
+    with torch.no_grad():
+        r = m(sample=[clips], encoder_hidden_states=enc, encoder_attention_mask=mask, pooled_projections=pooled,
+              timestep_ratio=t)[0]
+    o = flux_forward(m.state_dict(), cfg, clips, enc, mask, pooled, t)
+    assert o.shape == r.shape
+    assert (r - o).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item())
+
+
+def test_vae_oracle_at_released_width(ref):
+    """the decoder oracle against the reference at the released channel widths (512 / 512 / 256 / 128, three resnets per
+    block, 512-channel mid attention) on a small latent"""
+    from oracle import ref_harness as rh
+    from oracle.vae_oracle import vae_decode
+    cfg = dict(encoder_out_channels=16, decoder_in_channels=16,
+               encoder_block_out_channels=(32, 32, 64, 64), decoder_block_out_channels=(128, 256, 512, 512),
+               encoder_layers_per_block=(1, 1, 1, 1), decoder_layers_per_block=(3, 3, 3, 3))
+    v = rh.build_ref_vae(cfg, seed=55)
+    z = torch.randn(1, 16, 2, 6, 8, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        r = v.decode(z, temporal_chunk=False).sample
+    ocfg = dict(decoder_block_out_channels=(128, 256, 512, 512), decoder_layers_per_block=(3, 3, 3, 3),
+                decoder_spatial_up_sample=(True, True, True, False), decoder_temporal_up_sample=(True, True, True, False))
+    o = vae_decode({k: t for k, t in v.state_dict().items() if k.startswith(("decoder.", "post_quant_conv."))}, ocfg, z)
+    assert o.shape == r.shape
+    assert (r - o).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item())
+
+
+def test_mmdit_oracle_at_released_width(ref):
+    """the SD3-style variant at its released width (d = 1536, 24 heads), one joint block + the context_pre_only last block"""
+    from oracle import ref_harness as rh
+    from oracle.mmdit_oracle import mmdit_forward
+    from pyflow_hip import synth
+    cfg = dict(TINY_MMDIT, **dict(synth.SD3_MMDIT, num_layers=2))
+    m = rh.seed_weights(ref.PyramidDiffusionMMDiT(**cfg).eval(), 78)
+    g = torch.Generator().manual_seed(6)
+    clips = [torch.randn(2, 16, 2, 6, 10, generator=g), torch.randn(2, 16, 1, 12, 20, generator=g),
+             torch.randn(2, 16, 1, 12, 20, generator=g)]
+    enc = torch.randn(2, 24, 4096, generator=g)
+    mask = torch.zeros(2, 24, dtype=torch.long)
+    mask[0, :7] = 1
+    mask[1, :19] = 1
+    pooled = torch.randn(2, 2048, generator=g)
+    t = torch.tensor([431.5, 431.5])
+    with torch.no_grad():
+        r = m(sample=[clips], encoder_hidden_states=enc, encoder_attention_mask=mask, pooled_projections=pooled,
+              timestep_ratio=t)[0]
+    o = mmdit_forward(m.state_dict(), cfg, clips, enc, mask, pooled, t)
+    assert o.shape == r.shape
+    assert (r - o).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item())
