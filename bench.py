@@ -425,7 +425,8 @@ def main():
                                 "counted at the L2<->fabric interface incl. Infinity-Cache hits")
     value = frames_per_video * args.steps * (1 if use_sp else world) / dt
     res = {
-        "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling",
+        "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling" if args.workload.startswith("c3")
+        else f"video frames/sec (whole node) for {H}x{W} {frames_per_video}-frame T2V sampling ({args.workload}, not the headline metric)",
         "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True,
         # N > 1 default: ONE video over all GPUs (total work fixed) = strong scaling; the N = 1 line of the same sweep says
