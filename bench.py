@@ -37,6 +37,7 @@ WORKLOADS = {
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E (same guide)
+PMC_PROFILE = "r02_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the `traffic` fields are replayed from
 
 
 def build_pipeline(device, tiny=False, mmdit=False, stages=None):
@@ -211,6 +212,48 @@ def cpu_baseline(dcfg, dsd, threads):
                         f"total {est:.0f} s per 241-frame video"))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start one rank per GPU of this node (the reference's launcher is
+    torchrun, scripts/inference_multigpu.sh:15-23; the contract each rank sees is the same -- RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT, trainer_misc/utils.py:72-88) and wait for them.  Rank 0 owns stdout (the one
+    JSON line); the other ranks' stdout goes to stderr.  With fewer GPUs than ranks (a one-GPU test box) the ranks
+    share the GPUs and the transport falls to gloo: plumbing only, flagged in the JSON line."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PF_BENCH_LAUNCHER="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < n:
+        env.setdefault("PF_DIST_BACKEND", "gloo")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in alive:               # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,6 +271,9 @@ def main():
                     help="N > 1: sp = one video across all GPUs (default), replicas = one video per GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N` (no torchrun on the command line): this process becomes the launcher
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -236,6 +282,7 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     use_sp = world > 1 and args.parallelism == "sp"
+    comm_used = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -245,6 +292,7 @@ def main():
         if use_sp:      # must exist before the model is built (reference contract, inference_multigpu.py:34-39)
             from pyflow_hip import sp as sp_mod
             comm = sp_mod.init_sequence_parallel_group(sp_group_size=world)
+            comm_used = comm
             # every collective of the path once, with known values, before any model is built; if a rank cannot run it
             # all ranks agree to fall back to independent replicas (reported as such in the JSON line)
             ok = 1
@@ -347,10 +395,11 @@ def main():
         assert out.shape == (frames_per_video, H, W, 3) and out.dtype == torch.uint8 and not out.is_cuda
     else:
         assert out is None
+    peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, peak_gib], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
+        dt, peak_gib = t[0].item(), t[1].item()
     if rank != 0:
         return
     from pyflow_hip import ops
@@ -402,11 +451,15 @@ def main():
     finally:
         ops.PROFILER.enabled = False
     # L2 <-> fabric traffic per launch from the committed rocprofv3 --pmc passes (one full-width forward at L = 15 488)
+    pmc_path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_forward_maxL.json")) as f:
-            pm = json.load(f)["kernels"]
+        with open(pmc_path, "rb") as f:
+            raw = f.read()
+        pm = json.loads(raw)["kernels"]
+        import hashlib           # git blob id of the file the numbers are replayed from: a stale replay is visible
+        pmc_blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]
     except Exception:
-        pm = {}
+        pm, pmc_blob = {}, None
 
     def pmc_traffic(name):
         key = {"attention": "attn_kernel", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
@@ -421,9 +474,17 @@ def main():
             r["traffic"] = pmc_traffic(r["kernel"])
     if roof is not None and roof["traffic"] is not None:
         roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
-                                "the launches of one full-width forward at L=15488 (profiles/r02_pmc_forward_maxL.json); "
+                                f"the launches of one full-width forward at L=15488; REPLAYED from profiles/{PMC_PROFILE} "
+                                f"(git blob {pmc_blob}), not measured in this run; "
                                 "counted at the L2<->fabric interface incl. Infinity-Cache hits")
     value = frames_per_video * args.steps * (1 if use_sp else world) / dt
+    if dcfg is not None:          # what was actually built (tiny plumbing models and the MMDiT variant included)
+        d_model = dcfg["num_attention_heads"] * dcfg["attention_head_dim"]
+        n_par = sum(v.numel() for v in dsd.values()) / 1e9
+        model_desc = (f"SD3-style MMDiT ({n_par:.2f} B params, {dcfg['num_layers']} joint blocks, d={d_model})" if i2v else
+                      f"miniFLUX pyramid DiT ({n_par:.2f} B params, {dcfg['num_layers']}+{dcfg['num_single_layers']} blocks, d={d_model})")
+    else:
+        model_desc = "no DiT"
     res = {
         "metric": "video frames/sec (whole node) for 768p 241-frame T2V sampling" if args.workload.startswith("c3")
         else f"video frames/sec (whole node) for {H}x{W} {frames_per_video}-frame T2V sampling ({args.workload}, not the headline metric)",
@@ -433,7 +494,7 @@ def main():
         # the same; `--parallelism replicas` is the weak-scaling form
         "scaling": "strong" if (args.parallelism == "sp" and (use_sp or world == 1)) else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: miniFLUX pyramid DiT (1.97 B params, 8+16 blocks, d=1920) + CausalVideoVAE "
+        "config": {"workload": f"{args.workload}: {model_desc} + CausalVideoVAE "
                                f"tiled(256)/chunked(1) decode (the reference's save_memory schedule; four chunk windows per launch set), {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
                                "CFG 7.0/5.0, random-init weights, synthetic prompt embeddings"
                                + (" [TINY MODEL: plumbing only]" if args.tiny_model else ""),
@@ -446,15 +507,25 @@ def main():
     }
     if pipe is not None:
         res["config"]["launch_mode"] = getattr(pipe.dit, "launch_mode", "eager")
+    # device memory the timed region needed (torch allocator high-water mark, max over ranks): the tiled decode runs four
+    # tile lanes x four coalesced chunk windows, a hidden requirement of the headline number on a 288 GB part
+    res["peak_mem_gib"] = round(peak_gib, 1)
+    if world > 1:
+        backend = torch.distributed.get_backend()
+        res["launcher"] = "bench.py self-launch" if os.environ.get("PF_BENCH_LAUNCHER") == "self" else "external (torchrun)"
+        res["rccl_ranks"] = world if backend == "nccl" else 0
+        res["communicator"] = ("pf_comm (C-ABI RCCL communicator)" if getattr(comm_used, "backend", "") == "pf_comm" else
+                               f"torch.distributed ({backend}" + (" = RCCL)" if backend == "nccl" else
+                               "; ranks share GPUs, transport through the host: PLUMBING ONLY, not a measurement)"))
     if i2v:
         res["metric"] = "video frames/sec for 768p image-to-video sampling (config C4, not the headline metric)"
-        res["config"]["workload"] = (f"{args.workload}: SD3-style MMDiT (24 joint blocks, d=1536) generate_i2v + CausalVideoVAE "
+        res["config"]["workload"] = (f"{args.workload}: {model_desc} generate_i2v + CausalVideoVAE "
                                      f"tiled encode / decode, {H}x{W}, temp={temp} ({frames_per_video} frames), steps {stepsv}, "
                                      "CFG 7.0/4.0, random-init weights, synthetic prompt embeddings and image")
     if image_only:
         res["metric"] = "images/sec for 1024x1024 one-stage text-to-image sampling (config C1, not the headline metric)"
         res["unit"] = "images/s"
-        res["config"]["workload"] = (f"{args.workload}: miniFLUX, ONE pyramid stage (stages=[1], stage_range=[0,1]), {H}x{W}, "
+        res["config"]["workload"] = (f"{args.workload}: {model_desc}, ONE pyramid stage (stages=[1], stage_range=[0,1]), {H}x{W}, "
                                      f"{steps1[0]} steps, CFG 9.0, L = 4 224 tokens per forward, tiled VAE decode, random-init "
                                      "weights, synthetic prompt embeddings")
     if vae_only:
@@ -471,6 +542,10 @@ def main():
         res["roofline"] = dict(conv, note="dominant kernel family of the decode: implicit-GEMM CausalConv3d (MFMA-bound for C >= 128); "
                                           "GroupNorm passes against the HBM peak in roofline_other_kernels") if conv else None
         res["roofline_other_kernels"] = {k: v for k, v in extra.items() if k != "vae:conv3d"}
+    if args.tiny_model:           # a plumbing run must never read like the headline measurement
+        if "[TINY MODEL" not in res["config"]["workload"]:
+            res["config"]["workload"] += " [TINY MODEL: plumbing only]"
+        res["metric"] = "PLUMBING RUN with a tiny random model (not a measurement): " + res["metric"]
     if not args.no_cpu_baseline and world == 1 and not args.tiny_model and not i2v and not image_only and not vae_only:
         res["cpu_baseline"] = cpu_baseline(dcfg, dsd, os.cpu_count() or 1)
     print(json.dumps(res))

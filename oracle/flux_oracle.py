@@ -197,9 +197,11 @@ def flux_forward(sd, cfg, clips, enc, enc_mask, pooled, timestep, return_interme
         c, x = double_block(sd, f"transformer_blocks.{i}.", cfg, x, c, temb, mask, freqs)
         if i == 0:
             inter["x_after_double0"], inter["c_after_double0"] = x, c
+        inter.setdefault("blocks", []).append(torch.cat([c, x], dim=1))       # [text | image] rows after every block
     h = torch.cat([c, x], dim=1)
     for i in range(cfg["num_single_layers"]):
         h = single_block(sd, f"single_transformer_blocks.{i}.", cfg, h, temb, mask, freqs)
+        inter.setdefault("blocks", []).append(h)
     x = h[:, Lt:]
     inter["x_final"] = x
     e = _lin(sd, "norm_out.linear", F.silu(temb))

@@ -202,6 +202,46 @@ def generate_fixture():
                os.path.join(OUT, "generate_tiny_latents.pt"))
 
 
+class _Bf16TextEncoder:
+    """the harness's stub prompt encoder with bf16 outputs, as the reference's encoders return under `model_dtype='bf16'`"""
+
+    def __init__(self):
+        self.inner = rh.StubTextEncoder()
+
+    def to(self, *_a, **_k):
+        return self
+
+    def __call__(self, prompt, device):
+        e, m, p = self.inner(prompt, device)
+        return e.to(torch.bfloat16), m, p.to(torch.bfloat16)
+
+
+def generate_bf16_fixture():
+    """The trajectory production runs (`_round = True`): the UNMODIFIED reference's generate() with the DiT in bf16, bf16
+    prompt embeddings (so the latents are bf16: pyramid_dit_for_video_gen_pipeline.py:1100) under CPU bf16 autocast --
+    the reference's own inference setup (inference_multigpu.py:60-64: `torch.cuda.amp.autocast(dtype=bf16)`) moved to
+    the CPU.  Every rounding point of the host loop (CFG combine, Euler step with the 0-dim float64 sigma difference,
+    renoise, both pyramids, the bf16-rounded timestep) is therefore the reference's own."""
+    dit = build_dit().to(torch.bfloat16)
+    vae = build_vae()
+    pipe = rh.build_ref_pipeline(dit, vae, text_encoder=_Bf16TextEncoder())
+    rh.patch_block_noise(pipe, rh.NoiseStream(1))
+    H, W, temp = 64, 128, 4
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        lat = pipe.generate(prompt="a cat", height=H, width=W, temp=temp, num_inference_steps=[3, 3, 3],
+                            video_num_inference_steps=[2, 2, 2], guidance_scale=7.0, video_guidance_scale=5.0,
+                            generator=torch.Generator().manual_seed(0), output_type="latent")
+    assert lat.dtype == torch.bfloat16
+    te = pipe.text_encoder
+    pe, pm, pp = te("a cat, hyper quality, Ultra HD, 8K", None)
+    ne, nm, npool = te(NEG, None)
+    torch.save(dict(dit_cfg=synth.TINY_FLUX, dit_weight_seed=DIT_SEED,
+                    prompt_embeds=torch.cat([ne, pe]), prompt_mask=torch.cat([nm, pm]), pooled=torch.cat([npool, pp]),
+                    height=H, width=W, temp=temp, steps=[3, 3, 3], video_steps=[2, 2, 2], guidance=7.0,
+                    video_guidance=5.0, latent_seed=0, noise_seed=1, latents=lat),
+               os.path.join(OUT, "generate_tiny_latents_bf16.pt"))
+
+
 def scheduler_fixture():
     ref = rh.shims.load_reference()
     out = {}
@@ -224,6 +264,7 @@ if __name__ == "__main__":
     i2v_fixture()
     vae_fixture()
     generate_fixture()
+    generate_bf16_fixture()
     scheduler_fixture()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -33,7 +33,7 @@ struct AArgs {
     int Lp, L, H, B, Lt, nqt;
     int hs_qk;             // elements between consecutive heads in Q and K (64 = packed heads)
     int qt0;               // first 128-row query tile to compute (rows below are not needed by the caller)
-    int prio;              // tuning hook (PF_ATTN_PRIO): 0 no s_setprio, 1 around the MFMA groups, 2 around the softmax
+    int prio;              // 0 no s_setprio, 1 around the MFMA groups (what pf_attention_bf16 sets), 2 around the softmax
     const int* a_lo; const int* a_hi; const int* b_hi;
     const int* tile_kv_end;
     float sc;   // softmax scale * log2(e)

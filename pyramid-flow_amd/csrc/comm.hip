@@ -115,9 +115,16 @@ extern "C" int pf_comm_init(pf_comm** out, int rank, int world, const void* uniq
     memcpy(id.internal, unique_id_128, 128);
     const int rc = g_api.CommInitRank(&c->comm, world, id, rank);
     if (rc != 0) { delete c; return rccl_fail("pf_comm_init", rc); }
+    c->stream = nullptr;
+    c->ev_in = c->ev_out = nullptr;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) {
+        // give back whatever was created before the failure: the RCCL communicator, the stream, the first event
+        if (c->ev_out) hipEventDestroy(c->ev_out);
+        if (c->ev_in) hipEventDestroy(c->ev_in);
+        if (c->stream) hipStreamDestroy(c->stream);
+        g_api.CommDestroy(c->comm);
         delete c;
         return pf_set_err("pf_comm_init: stream / event creation failed");
     }

@@ -14,6 +14,22 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 #define PF_DEVICE __device__ __forceinline__
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: set it once per (call site, device),
+// thread-safe, so that a C-ABI host driving several GPUs from one process gets its > 64 KiB LDS launches on every device.
+// `kernel` may be a parenthesised template-id.
+#include <atomic>
+#define PF_SET_MAX_LDS_ONCE(kernel, bytes)                                                                          \
+    do {                                                                                                            \
+        static std::atomic<unsigned long long> pf_done_{0ull};                                                      \
+        int pf_dev_ = 0;                                                                                            \
+        (void)hipGetDevice(&pf_dev_);                                                                               \
+        const unsigned long long pf_bit_ = 1ull << (pf_dev_ & 63);                                                  \
+        if (!(pf_done_.load(std::memory_order_acquire) & pf_bit_)) {                                                \
+            (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));  \
+            pf_done_.fetch_or(pf_bit_, std::memory_order_release);                                                  \
+        }                                                                                                           \
+    } while (0)
+
 // Direct global -> LDS DMA, 16 bytes per lane.  LDS destination = wave-uniform `lds_base` + lane*16
 // (the hardware adds the lane offset); the global source is per lane.
 PF_DEVICE void glds16(const void* gsrc, void* lds_base) {

@@ -5,8 +5,9 @@
 //     input frame is staged in LDS (81 KiB, LDS-DMA, XOR-swizzled per pixel) and feeds the three output frames it
 //     belongs to (temporal taps 2, 1, 0 of outputs s-2, s-1, s): three rolling accumulator sets, each input frame is
 //     read once per tile instead of 27 times;
-//   * v_mfma_f32_16x16x32_bf16 with the FILTERS as the 16-row operand (rows >= 4 are zero registers, rows 0..3 come from
-//     a 27-KiB LDS copy of the first four filter rows) and 16 pixels of a tile row as the columns: a lane of the first
+//   * v_mfma_f32_16x16x32_bf16 with the FILTERS as the 16-row operand (rows >= 8 are zero registers, rows 0..7 come from
+//     a 54-KiB LDS copy of the first eight filter rows: every column the 8-channel output pitch can hold is computed, so
+//     any n_valid in 1..8 is exact) and 16 pixels of a tile row as the columns: a lane of the first
 //     two 16-lane groups ends up with output channels 0-3 / 4-7 of its pixel = one 8-byte store each ([T][H][W][8] bf16,
 //     the layout the blend / uint8 kernels read);
 //   * K order per output = (dt, dh, dw, c) ascending, the implicit GEMM's order.
@@ -22,7 +23,8 @@ constexpr int HS = TS + 2;                    // halo side
 constexpr int CIN = 128;
 constexpr int HALO_BYTES = HS * HS * CIN * 2; // 82 944 = 81 pieces of 1 KiB
 constexpr int WROW = 27 * CIN * 2 + 32;       // bytes per filter row in LDS (+32: rows land on different banks)
-constexpr int SMEM = HALO_BYTES + 4 * WROW;
+constexpr int NROW = 8;                       // filter rows staged and multiplied (= the output pitch)
+constexpr int SMEM = HALO_BYTES + NROW * WROW;
 
 struct NArgs {
     const bf16_t* X; const bf16_t* Wt; const float* bias; bf16_t* Y;
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(256, 1) void conv_narrow_kernel(const NArgs p) {
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * TS, x0 = tx * TS;
 
-    // ---- filter rows 0..3 -> LDS (16-byte pieces, plain loads: 27 KiB once per workgroup)
-    for (int i = tid; i < 4 * (27 * CIN / 8); i += 256) {
+    // ---- filter rows 0..7 -> LDS (16-byte pieces, plain loads: 54 KiB once per workgroup)
+    for (int i = tid; i < NROW * (27 * CIN / 8); i += 256) {
         const int row = i / (27 * CIN / 8), ck = i - row * (27 * CIN / 8);
         *(u32x4_t*)(wl + row * WROW + ck * 16) = *(const u32x4_t*)(p.Wt + (long long)row * p.ldw + ck * 8);
     }
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void conv_narrow_kernel(const NArgs p) {
                 for (int a = 0; a < 3; ++a) {
                     const int dt = 2 - a;
                     u32x4_t raw = (u32x4_t){0u, 0u, 0u, 0u};
-                    if (li < 4) raw = *(const u32x4_t*)(wl + li * WROW + (((dt * 9 + tap) * CIN) + kk * 32 + kq * 8) * 2);
+                    if (li < NROW) raw = *(const u32x4_t*)(wl + li * WROW + (((dt * 9 + tap) * CIN) + kk * 32 + kq * 8) * 2);
                     wf[a] = __builtin_bit_cast(bf16x8_t, raw);
                 }
 #pragma unroll
@@ -132,21 +134,19 @@ __global__ __launch_bounds__(256, 1) void conv_narrow_kernel(const NArgs p) {
 
 int pf_set_err(const char* m);
 
-// does this convolution fit the narrow kernel?  (3x3x3, 128 input channels, at most 8 output columns stored with pitch 8,
-// unit strides, no shortcut add, 16-pixel-aligned frame)
+// does this convolution fit the narrow kernel?  (3x3x3, 128 input channels, 1..8 output channels -- the kernel multiplies
+// filter rows 0..7, the weight matrix has >= 8 rows (N) -- stored with pitch 8, unit strides, no shortcut add,
+// 16-pixel-aligned frame).  n_valid == 0 means "all N columns" in pf_conv_desc and is NOT narrow.
 bool pf_conv_narrow_supports(const pf_conv_desc* d) {
-    return d->kt == 3 && d->kh == 3 && d->kw == 3 && d->Cin == CIN && d->n_valid <= 8 && d->Cout_pitch == 8 && d->Cg == 8 &&
+    return d->kt == 3 && d->kh == 3 && d->kw == 3 && d->Cin == CIN && d->n_valid >= 1 && d->n_valid <= NROW && d->N >= NROW &&
+           d->Cout_pitch == 8 && d->Cg == 8 &&
            d->st == 1 && d->sh == 1 && d->sw == 1 && !(d->flags & PF_GEMM_GATE_RES) && d->out_t_shift == 0 &&
            (d->in_sh == 0 || d->in_sh == 1) && (d->in_sw == 0 || d->in_sw == 1) && (d->in_st == 0 || d->in_st == 1) &&
            d->H % TS == 0 && d->W_ % TS == 0 && d->T >= 1;
 }
 
 int pf_conv_narrow_launch(const pf_conv_desc* d, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    PF_SET_MAX_LDS_ONCE(conv_narrow_kernel, SMEM);
     NArgs a;
     a.X = (const bf16_t*)d->X; a.Wt = (const bf16_t*)d->W; a.bias = d->bias; a.Y = (bf16_t*)d->Y;
     a.T = d->T; a.H = d->H; a.W = d->W_; a.Hp = d->Hp; a.Wp = d->Wp;

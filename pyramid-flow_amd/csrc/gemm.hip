@@ -349,11 +349,7 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
             grid *= ks;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        attr_set = true;
-    }
+    PF_SET_MAX_LDS_ONCE((gemm_kernel<false>), SMEM_BYTES);
     hipLaunchKernelGGL(gemm_kernel<false>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
     if (a.ksplit > 1) {
         const long long total = (long long)d->batch * d->M * (d->N / 8);

@@ -317,11 +317,7 @@ template <int BN, bool CONV, int V>
 int launch(const Args& a, hipStream_t stream) {
     const int grid = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
     constexpr int SM = (V == 4) ? Cfg<BN>::SMEM3 : Cfg<BN>::SMEM;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm256_kernel<BN, CONV, V>, hipFuncAttributeMaxDynamicSharedMemorySize, SM);
-        attr_set = true;
-    }
+    PF_SET_MAX_LDS_ONCE((gemm256_kernel<BN, CONV, V>), SM);
     hipLaunchKernelGGL((gemm256_kernel<BN, CONV, V>), dim3(grid), dim3(512), SM, stream, a);
     return 0;
 }

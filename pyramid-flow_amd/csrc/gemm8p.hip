@@ -501,11 +501,7 @@ int g_num_cu = 0;
 
 template <bool CONV, int EPI>
 int launch(const Args& a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm8p_kernel<CONV, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
-    }
+    PF_SET_MAX_LDS_ONCE((gemm8p_kernel<CONV, EPI>), SMEM);
     if (!g_num_cu) {
         int dev = 0;
         hipGetDevice(&dev);

@@ -108,6 +108,7 @@ class _BlockOp(DeviceModuleAPI):
         eng.cfg, eng._ws, eng._ctx, eng._mod_cache = cfg, {}, None, None
         eng.overlap_text, eng.skip_dead_rows, eng._side = False, False, None
         eng.launch_mode, eng._ws_gen = "eager", 0
+        eng._listed_plans = None
         self._eng = eng
         return self
 
@@ -155,8 +156,9 @@ class FluxTransformerBlock(_BlockOp):
         h = self._fill(plan, encoder_hidden_states, hidden_states)
         self._eng._run_blocks(plan, self._mod(temb), last_block_tail=False)
         pre_only = self._eng.w.dbl[0]["pre_only"]
-        enc_out = None if pre_only else h[:, :Lt].to(encoder_hidden_states.dtype)
-        return enc_out, h[:, Lt:].to(hidden_states.dtype)
+        # copies, never views of the engine's `hidden` workspace: the next call of this (or any) block overwrites it
+        enc_out = None if pre_only else h[:, :Lt].to(encoder_hidden_states.dtype, copy=True)
+        return enc_out, h[:, Lt:].to(hidden_states.dtype, copy=True)
 
     __call__ = forward
 
@@ -193,6 +195,6 @@ class FluxSingleTransformerBlock(_BlockOp):
         plan = _MaskPlan(_one(attention_mask), _one(image_rotary_emb), Lt, L - Lt, self.dev)
         h = self._fill(plan, None, hidden_states)
         self._eng._run_blocks(plan, self._mod(temb), last_block_tail=False)
-        return h.to(hidden_states.dtype)
+        return h.to(hidden_states.dtype, copy=True)          # a copy: `h` is the engine's workspace
 
     __call__ = forward

@@ -14,6 +14,7 @@ import time
 import torch
 
 from . import lib as L
+from . import ops
 from .lib import check
 from .sp import starts_of
 
@@ -80,17 +81,31 @@ class NativeComm:
             self.comm = comm
 
         def wait(self):
-            """the CURRENT stream waits for the exchange on the device (no host sync), like a c10d work handle"""
+            """the CURRENT stream waits for the exchange on the device (no host sync), like a c10d work handle.
+            While a launch list is being recorded the wait becomes a list entry on the recorder's current stream slot."""
+            rec = ops.RECORDER
+            if rec is not None:
+                check(self.comm._lib.pf_cmdlist_comm_wait(rec.h, self.comm._h, C.c_int(rec.slot)))
+                return
             check(self.comm._lib.pf_comm_wait(self.comm._h, NativeComm._cur()))
+
+    def _no_recording(self, what):
+        # only the Ulysses exchange + its wait have list entries (pf_cmdlist_all_to_all_v / pf_cmdlist_comm_wait): any
+        # other collective issued while recording would run NOW, out of order with the recorded kernels
+        assert ops.RECORDER is None, f"NativeComm.{what} cannot be recorded into a launch list"
 
     def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
         esz = send.element_size()
         P = self.world
         arr = C.c_longlong * P
         so, ro = starts_of(send_splits), starts_of(recv_splits)
-        check(self._lib.pf_all_to_all_v(self._h, C.c_void_p(send.data_ptr()), arr(*[s * esz for s in send_splits]),
-                                        arr(*[o * esz for o in so]), C.c_void_p(recv.data_ptr()),
-                                        arr(*[r * esz for r in recv_splits]), arr(*[o * esz for o in ro]), self._cur()))
+        a = (C.c_void_p(send.data_ptr()), arr(*[s * esz for s in send_splits]), arr(*[o * esz for o in so]),
+             C.c_void_p(recv.data_ptr()), arr(*[r * esz for r in recv_splits]), arr(*[o * esz for o in ro]))
+        rec = ops.RECORDER
+        if rec is not None:      # recorded: ordered after what the list holds so far on the current slot, replayed from C
+            check(self._lib.pf_cmdlist_all_to_all_v(rec.h, self._h, *a, C.c_int(rec.slot)))
+        else:
+            check(self._lib.pf_all_to_all_v(self._h, *a, self._cur()))
         h = self._Handle(self)
         if async_op:
             return h
@@ -98,12 +113,14 @@ class NativeComm:
         return None
 
     def all_reduce(self, t):
+        self._no_recording("all_reduce")
         assert t.dtype == torch.float32 and t.is_contiguous()
         check(self._lib.pf_all_reduce_sum_f32(self._h, C.c_void_p(t.data_ptr()), C.c_longlong(t.numel()), self._cur()))
         self._Handle(self).wait()
         return t
 
     def broadcast(self, t, src=0):
+        self._no_recording("broadcast")
         assert t.is_contiguous()
         check(self._lib.pf_broadcast_bytes(self._h, C.c_void_p(t.data_ptr()), C.c_longlong(t.numel() * t.element_size()),
                                            C.c_int(src), self._cur()))
@@ -111,6 +128,7 @@ class NativeComm:
         return t
 
     def shift(self, send_t, recv_t):
+        self._no_recording("shift")
         s_ = send_t.contiguous()
         assert recv_t.is_contiguous()
         check(self._lib.pf_halo_send_recv(self._h, C.c_void_p(s_.data_ptr()), C.c_void_p(recv_t.data_ptr()),
@@ -119,6 +137,7 @@ class NativeComm:
 
     def all_gather_v(self, send, recv, counts):
         """recv <- concatenation of every rank's `send` (element counts per rank in `counts`)"""
+        self._no_recording("all_gather_v")
         esz = send.element_size()
         arr = C.c_longlong * self.world
         check(self._lib.pf_all_gather_v(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
@@ -126,6 +145,15 @@ class NativeComm:
                                         self._cur()))
         self._Handle(self).wait()
         return recv
+
+    def selftest(self, device):
+        """every collective of the sampling path once with known values (SPComm.selftest over this transport)"""
+        from .sp import SPComm
+        return SPComm.selftest(self, device)
+
+    def warm_p2p(self, device):
+        from .sp import SPComm
+        return SPComm.warm_p2p(self, device)
 
     def barrier(self):
         t = torch.zeros(1, dtype=torch.float32, device="cuda")
@@ -151,6 +179,7 @@ class NativeComm:
 
     def all_to_all_pair(self, send, recv, send_splits, recv_splits, peer):
         """two-rank exchange (only `peer` and this rank take part: grouped ncclSend / ncclRecv involve just the pair)"""
+        self._no_recording("send / recv")
         ref = send if send is not None else recv
         esz = ref.element_size()
         arr = C.c_longlong * self.world

@@ -206,6 +206,7 @@ class FluxEngine(DeviceModuleAPI):
         #   "graph": the same list captured into a hipGraph after its first replay (one hipGraphLaunch per forward)
         self.launch_mode = "graph"
         self._ws_gen = 0                # bumped when a workspace buffer is re-allocated (recorded pointers go stale)
+        self._listed_plans = None       # weak set of the plans that hold a launch list of this engine
 
     def _side_stream(self):
         if self._side is None:
@@ -220,6 +221,10 @@ class FluxEngine(DeviceModuleAPI):
                 else torch.empty(numel, dtype=dtype, device=self.dev)
             self._ws[name] = t
             self._ws_gen += 1
+            # every recorded list / captured hipGraph of this engine now points at freed storage: drop them NOW, not when
+            # their plan happens to run again (a stale graph exec would otherwise stay attached to a cached plan)
+            for p_ in list(getattr(self, "_listed_plans", None) or ()):
+                p_.__dict__.pop("_launch_list", None)
         return t
 
     def make_plan(self, clip_shapes, enc_mask):
@@ -318,7 +323,11 @@ class FluxEngine(DeviceModuleAPI):
         n_mod = plan.B * w.n_mod
         for _ in range(2):
             ms = self._buf("mod_fixed", n_mod, torch.float32)
-            key = (id(self), self._ws_gen, self.overlap_text, self.skip_dead_rows, self.launch_mode != "list")
+            # what a recorded sequence depends on besides the plan: the workspace pointers (generation), the stream
+            # structure, the row restriction of the last block, and the GEMM dispatch policy / split-K state in force
+            # when the descriptors were recorded (pf_gemm_set_policy picks kernels at record time)
+            key = (id(self), self._ws_gen, self.overlap_text, self.skip_dead_rows, self.launch_mode != "list",
+                   ops.POLICY_GEN)
             ent = getattr(plan, "_launch_list", None)
             if ent is not None and ent[0] == key:
                 break
@@ -329,6 +338,10 @@ class FluxEngine(DeviceModuleAPI):
             if key[1] != self._ws_gen:        # a workspace buffer was (re)allocated while recording: pointers of the
                 continue                      # earlier entries may be stale -> record again, now without allocations
             plan._launch_list = ent = (key, cl, out)
+            if getattr(self, "_listed_plans", None) is None:
+                import weakref
+                self._listed_plans = weakref.WeakSet()
+            self._listed_plans.add(plan)
             break
         else:
             raise RuntimeError("launch list: the workspace did not settle")
@@ -493,9 +506,12 @@ class FluxEngine(DeviceModuleAPI):
             ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                      res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                      gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + r0 * 4 * d, c_off=r0 * d, r_off=r0 * d)
-            if debug is not None and "hidden_d0" not in debug:
+            if debug is not None and ("hidden_d0" not in debug or "blocks" in debug):
                 join(1, 0)
-                debug["hidden_d0"] = hidden[:B * L * d].view(B, L, d).clone()
+                snap = hidden[:B * L * d].view(B, L, d).clone()
+                debug.setdefault("hidden_d0", snap)
+                if "blocks" in debug:             # caller asked for the state after EVERY block (parity tests)
+                    debug["blocks"].append(snap)
         join(1, 0)
 
         n_cur = plan.n_cur
@@ -528,6 +544,8 @@ class FluxEngine(DeviceModuleAPI):
             ops.gemm(big, blk["out"][0], hidden, L, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=2 * d)
+            if debug is not None and "blocks" in debug:
+                debug["blocks"].append(hidden[:B * L * d].view(B, L, d).clone())
         if debug is not None:
             debug["hidden_final"] = hidden[:B * L * d].view(B, L, d).clone()
 

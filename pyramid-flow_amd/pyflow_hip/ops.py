@@ -82,10 +82,15 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     PROFILER.launch(name, 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
 
 
+POLICY_GEN = 0          # bumped by every gemm_set_policy: recorded launch lists / hipGraphs hold the kernels chosen at record time
+
+
 def gemm_set_policy(force):
     """0 auto | -1 128x128 kernel only | 128/192/256 force the 256xBN kernel | 8 / -8 force / forbid the persistent
     256x256 kernel gemm8p (pf_gemm_set_policy)."""
+    global POLICY_GEN
     check(L.load().pf_gemm_set_policy(C.c_int(force)))
+    POLICY_GEN += 1
 
 
 LOG2E = 1.4426950408889634

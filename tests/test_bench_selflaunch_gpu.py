@@ -1,0 +1,37 @@
+"""`python bench.py --gpus N` from a bare shell (no torchrun on the command line): bench.py starts the ranks itself
+(SURVEY 8d contract; the reference's launcher is torchrun, scripts/inference_multigpu.sh:15-23) and rank 0 prints ONE
+JSON line.  On the one-GPU test box the two ranks share the GPU and the transport falls to gloo (plumbing, flagged in
+the line); the kernels, the sequence-parallel engine and the tile-parallel decode are the real ones."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "smoke_128p_17f",
+                        "--tiny-model", "--no-cpu-baseline"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_self_launch_sequence_parallel_two_ranks():
+    r = _run([])
+    assert r["n_gpus"] == 2 and r["launcher"] == "bench.py self-launch" and r["scaling"] == "strong"
+    assert r["config"]["parallelism"].startswith("sp2") and r["value"] > 0 and r["peak_mem_gib"] > 0
+    assert r["metric"].startswith("PLUMBING RUN") and "TINY MODEL" in r["config"]["workload"]
+    assert "communicator" in r and "rccl_ranks" in r
+
+
+def test_self_launch_replicas_two_ranks():
+    r = _run(["--parallelism", "replicas"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "replicas" in r["config"]["parallelism"]

@@ -348,3 +348,17 @@ def test_mmdit_oracle_at_released_width(ref):
     o = mmdit_forward(m.state_dict(), cfg, clips, enc, mask, pooled, t)
     assert o.shape == r.shape
     assert (r - o).abs().max().item() <= 1e-4 * max(1.0, r.abs().max().item())
+
+
+def test_bf16_trajectory_fixture_is_the_references(ref, tmp_path, monkeypatch):
+    """tests/golden/generate_tiny_latents_bf16.pt (what the GPU's `_round = True` trajectory is compared with) is
+    reproduced bit for bit by re-running the unmodified reference with a bf16 DiT under CPU bf16 autocast."""
+    import os
+    from oracle import gen_golden as gg
+    committed = torch.load(os.path.join(gg.OUT, "generate_tiny_latents_bf16.pt"))
+    monkeypatch.setattr(gg, "OUT", str(tmp_path))
+    gg.generate_bf16_fixture()
+    fresh = torch.load(os.path.join(str(tmp_path), "generate_tiny_latents_bf16.pt"))
+    assert fresh["latents"].dtype == torch.bfloat16
+    assert torch.equal(fresh["latents"], committed["latents"])
+    assert torch.equal(fresh["prompt_embeds"], committed["prompt_embeds"])

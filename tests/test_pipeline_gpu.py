@@ -81,3 +81,28 @@ def test_one_stage_image_generation_vs_oracle():
                            stages=(1,), sched_kwargs=dict(stages=1, stage_range=[0, 1]))
     assert lat.shape == ref.shape == (1, 16, 1, 16, 16)
     assert rel_l2(lat.float().cpu(), ref) < 5e-2
+
+
+def test_generate_bf16_trajectory_vs_reference_fixture():
+    """The trajectory production and bench.py run (`_round = True`: bf16 prompt embeddings -> bf16 latents): latents per
+    unit against the fixture the UNMODIFIED reference produced with a bf16 DiT under CPU bf16 autocast
+    (oracle/gen_golden.py::generate_bf16_fixture).  The start noise is drawn in bf16 by the caller's generator exactly as
+    randn_tensor does (pipeline.py:694), so both sides start from the same bits.  Tolerance: SURVEY 8c, rel-L2 <= 5e-2."""
+    from pyflow_hip import synth
+    from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
+    from oracle.ref_harness import NoiseStream
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "generate_tiny_latents_bf16.pt"))
+    assert g["prompt_embeds"].dtype == torch.bfloat16 and g["latents"].dtype == torch.bfloat16
+    dsd = round_sd(synth.random_state_dict(synth.flux_param_shapes(g["dit_cfg"]), seed=g["dit_weight_seed"], std=0.05, lively=True))
+    pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=g["dit_cfg"], model_name="pyramid_flux", load_vae=False)
+    pipe.block_noise_fn = NoiseStream(g["noise_seed"]).block_noise
+    lat = pipe.generate(prompt_embeds=_embeds(g), height=g["height"], width=g["width"], temp=g["temp"],
+                        num_inference_steps=g["steps"], video_num_inference_steps=g["video_steps"],
+                        guidance_scale=g["guidance"], video_guidance_scale=g["video_guidance"],
+                        generator=torch.Generator().manual_seed(g["latent_seed"]), output_type="latent")
+    assert pipe._round and lat.dtype == torch.bfloat16 and lat.shape == g["latents"].shape
+    ref = g["latents"].float()
+    per_unit = [rel_l2(lat[:, :, u].float().cpu(), ref[:, :, u]) for u in range(ref.shape[2])]
+    print("bf16 trajectory rel-L2 per unit vs reference fixture:", [f"{e:.3e}" for e in per_unit])
+    assert max(per_unit) < 5e-2
+    assert rel_l2(lat.float().cpu(), ref) < 5e-2

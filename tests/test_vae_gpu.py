@@ -66,3 +66,37 @@ def test_uint8_frames_vs_oracle():
     assert u8.shape == ref.shape and u8.dtype == torch.uint8
     diff = (u8.int() - ref.int()).abs()
     assert diff.float().mean() < 2.0 and diff.max() <= 12      # bf16 activations vs fp32 oracle on a 0..255 scale
+
+
+@pytest.mark.parametrize("co", [1, 3, 4, 5, 8])
+def test_narrow_conv_every_channel_count_vs_conv3d(co):
+    """conv_narrow_kernel (csrc/convnarrow.hip) multiplies filter rows 0..7: any 3x3x3, 128-input-channel CausalConv3d
+    with 1..8 output channels stored at pitch 8 is exact through it -- against torch's fp32 conv3d with the causal
+    padding of modeling_causal_conv.py:116-146 and against the generic implicit-GEMM path on the same descriptor."""
+    import torch.nn.functional as F
+    from pyflow_hip import ops
+    from pyflow_hip.vae import PBuf, ConvW, conv
+    T, H, W, Ci = 3, 32, 48, 128
+    g = torch.Generator().manual_seed(40 + co)
+    x = torch.randn(1, Ci, T, H, W, generator=g).to(torch.bfloat16).float()
+    w = (torch.randn(co, Ci, 3, 3, 3, generator=g) * 0.05).to(torch.bfloat16).float()
+    b = torch.randn(co, generator=g)
+    ref = F.conv3d(F.pad(x, (1, 1, 1, 1, 2, 0)), w, b)[0].permute(1, 2, 3, 0)          # [T, H, W, co]
+    src = PBuf("x", T, H, W, Ci, "cuda")
+    v = src.t.view(T + 2, H + 2, W + 2, src.Cp)
+    v[2:, 1:-1, 1:-1, :Ci] = x[0].permute(1, 2, 3, 0).to("cuda", torch.bfloat16)
+    src.cur = T
+    cw = ConvW(w, b, "cuda")
+    outs = {}
+    for name, policy in (("narrow", 3), ("generic", -3)):
+        out = torch.full((T, H, W, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_set_policy(policy)
+        try:
+            conv(src, None, cw, T, dst_raw=(out, H, W, 8, 0))
+        finally:
+            ops.gemm_set_policy(3)
+        outs[name] = out.float().cpu()
+        assert rel_l2(outs[name][..., :co], ref) < 5e-3, name
+    assert torch.isfinite(outs["narrow"]).all()                  # every one of the 8 pitch columns was written
+    assert (outs["narrow"][..., co:] == 0).all()                 # ... the padding columns with zero filters and zero bias
+    assert rel_l2(outs["narrow"][..., :co], outs["generic"][..., :co]) < 2e-3
