@@ -125,11 +125,18 @@ def test_vae_untiled_768p_decode_vs_oracle():
     assert out.shape == ref.shape and err < 2e-2
 
 
-def test_vae_untiled_768p_chunked_equals_unchunked():
-    """three latent frames -> 17 frames of 768 x 1280, un-tiled: the chunked schedule ([2] + [1] latent frames with the
-    cache slots between the chunks) and the single pass are the same arithmetic on the same rows (SURVEY appendix B:
-    chunked vs unchunked 5e-6 in fp32); frame 0 equals the one-latent decode's frame (causality), which the previous
-    test pins to the oracle."""
+def _per_frame(a, b):
+    return [rel_l2(a[:, :, f], b[:, :, f]) for f in range(a.shape[2])]
+
+
+def test_vae_untiled_768p_chunked_vs_unchunked():
+    """three latent frames -> 17 frames of 768 x 1280, un-tiled: the chunked schedule ([2] + [1] latent frames, cache slots
+    between the chunks) against the single pass, frame by frame.  The two are the same arithmetic in exact numbers
+    (5e-6 in fp32) but not bit-identical in bf16: the launch shapes differ (split-K of the skinny
+    mid-block GEMMs, atomics order of the GroupNorm sums), fp32-ulp differences flip bf16 roundings and the flips
+    de-correlate over ~60 layers up to the bf16 noise floor (the distance of either to the fp32 oracle, 1.3e-2).  What
+    the test pins is that NO frame is worse than that floor -- a wrong cache frame at the chunk boundary is an O(1)
+    error in frames 9..16 -- and that frame 0 is the one-latent decode's frame (causality; pinned to the oracle above)."""
     vae, _, _ = _vae()
     vae.chunk_coalesce = 1               # the reference's own schedule: window_size latent frames per chunk
     z = torch.randn(1, 16, 3, 96, 160, generator=torch.Generator().manual_seed(34)).to(torch.bfloat16).float().cuda()
@@ -137,6 +144,28 @@ def test_vae_untiled_768p_chunked_equals_unchunked():
     assert full.shape == (1, 3, 17, 768, 1280)
     assert torch.isfinite(full).all()
     chunked = vae.decode(z, temporal_chunk=True, window_size=1).sample.float().cpu()
-    assert rel_l2(chunked, full) < 2e-3
+    pf = _per_frame(chunked, full)
+    print("VAE un-tiled 768p, 3 latent frames, chunked vs single pass, rel-L2 per frame:", " ".join(f"{e:.2e}" for e in pf))
+    assert max(pf) < 2e-2
     one = vae.decode(z[:, :, :1].contiguous(), temporal_chunk=False).sample.float().cpu()
-    assert rel_l2(full[:, :, :1], one) < 2e-3
+    assert rel_l2(full[:, :, :1], one) < 2e-2 and rel_l2(chunked[:, :, :1], one) < 2e-2
+
+
+def test_vae_released_width_three_latents_chunked_and_unchunked_vs_oracle():
+    """the same comparison where the fp32 oracle is affordable for all 17 frames (32 x 32 latent, released widths):
+    chunked and single-pass decodes are each within the bf16 tolerance of the oracle in EVERY frame, i.e. the chunk
+    boundary (frames 9..16 come from the second chunk's cache slots) is as exact as the interior."""
+    from oracle.vae_oracle import vae_decode
+    vae, sd, ocfg = _vae()
+    vae.chunk_coalesce = 1
+    z = torch.randn(1, 16, 3, 32, 32, generator=torch.Generator().manual_seed(35)).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = vae_decode(sd, ocfg, z)
+    assert ref.shape == (1, 3, 17, 256, 256)
+    full = vae.decode(z.cuda(), temporal_chunk=False).sample.float().cpu()
+    chunked = vae.decode(z.cuda(), temporal_chunk=True, window_size=1).sample.float().cpu()
+    e_full, e_chunk, e_between = _per_frame(full, ref), _per_frame(chunked, ref), _per_frame(chunked, full)
+    print("single pass vs oracle per frame:", " ".join(f"{e:.2e}" for e in e_full))
+    print("chunked     vs oracle per frame:", " ".join(f"{e:.2e}" for e in e_chunk))
+    print("chunked vs single pass        :", " ".join(f"{e:.2e}" for e in e_between))
+    assert max(e_full) < 2e-2 and max(e_chunk) < 2e-2
