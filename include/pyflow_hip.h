@@ -123,8 +123,20 @@ typedef struct {
                           multiple of 128): the last block only feeds the current frame's rows to the output */
     int q_prescaled;   /* 1: Q was already multiplied by scale*log2(e) (pf_qk_norm_rope q_scale): `scale` is ignored and
                           the scores are used as base-2 exponents directly (saves one FMA per score) */
+    /* optional scratch (pf_attention_workspace_bytes; NULL / 0 = none).  With it, large pre-scaled problems run as a PAIR of
+     * launches of the 64-rows-per-wave kernel (csrc/attention_w64.h): a pass without any running row maximum (exact while
+     * every row's largest base-2 score stays within about +-100 of zero: q.k after QK-RMSNorm is bounded by 11.5 x the
+     * norm gains) that flags, per wave, rows whose softmax denominator came out non-finite or vanishing, and a pass with
+     * the running maximum that recomputes flagged workgroups only (it returns at once otherwise).  Must not be shared by
+     * attention launches that may overlap. */
+    void* workspace;
+    long long workspace_bytes;
 } pf_attn_desc;
 int pf_attention_bf16(const pf_attn_desc* d, pf_stream_t stream);
+long long pf_attention_workspace_bytes(int B, int H, int L);
+/* which kernel pf_attention_bf16 would run for this descriptor: 64 = the 64-rows-per-wave fast + fix-up pair, 32 = the
+ * 32-rows-per-wave kernel (tests assert that the shapes of the benchmark take the pair) */
+int pf_attention_which(const pf_attn_desc* d);
 int pf_v_transpose(const void* V, void* Vt, int ldv, long long strideV, long long strideVt_b, long long strideVt_h,
                    int B, int H, int L, int Lp, int head_stride /* 0 = 64 */, pf_stream_t stream);
 

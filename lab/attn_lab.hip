@@ -45,7 +45,7 @@ namespace lab {
 //   4  no LDS fragment reads after the first tile
 //   8  no MFMAs (accumulators passed through an empty asm so the dependent code stays)
 //   16 s_memtime stamps around the phases of a tile (sums per wave written to `dbg`)
-enum { A_NOSM = 1, A_NOSYNC = 2, A_NOLDS = 4, A_NOMFMA = 8, A_STAMP = 16 };
+enum { A_NOSM = 1, A_NOSYNC = 2, A_NOLDS = 4, A_NOMFMA = 8, A_STAMP = 16, A_NOMAX = 32 };   // A_NOMAX: no row maximum, no reference (m = 0)
 constexpr int NPH = 8;
 
 template <int ABL, int OCC>
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, OCC) void attn_abl_kernel(const AArgs p, unsig
         } else {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][0], qf[0], negm, 0, 0, 0);
+            for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i][0], qf[0], (ABL & A_NOMAX) ? f32x16_t{0.f} : negm, 0, 0, 0);
 #pragma unroll
             for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256, OCC) void attn_abl_kernel(const AArgs p, unsig
                     }
             }
             float mt = s[0][0];
+            if (!(ABL & A_NOMAX)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -212,8 +213,9 @@ __global__ __launch_bounds__(256, OCC) void attn_abl_kernel(const AArgs p, unsig
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
                 mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
+            }
             const bool seen = mt > NINF;
-            if (__builtin_amdgcn_ballot_w64(mt > DEFER || (fresh && seen)) != 0) {
+            if (!(ABL & A_NOMAX) && __builtin_amdgcn_ballot_w64(mt > DEFER || (fresh && seen)) != 0) {
                 const float delta = fresh ? (seen ? mt : 0.f) : fmaxf(mt, 0.f);
                 const float alpha = fresh ? 1.f : __builtin_amdgcn_exp2f(-delta);
                 fresh = fresh && !seen;
@@ -398,6 +400,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_te, pl.tile_end.size() * 4));
     const size_t nwg_max = (size_t)pl.nqt * H * B;
     CK(hipMalloc(&d_dbg, nwg_max * 4 * lab::NPH * 4));
+    int* d_flags;
+    CK(hipMalloc(&d_flags, nwg_max * 4 * 4));
+    CK(hipMemset(d_flags, 0xff, nwg_max * 4 * 4));
     CK(hipMemcpy(dqkv, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dvt, 0, (size_t)B * H * 64 * Lp * 2));
     CK(hipMemcpy(d_alo, pl.a_lo.data(), pl.a_lo.size() * 4, hipMemcpyHostToDevice));
@@ -433,6 +438,8 @@ int main(int argc, char** argv) {
     vars.push_back({name, [&] { hipLaunchKernelGGL((lab::attn_abl_kernel<abl, occ>), dim3(grid), dim3(256), 0, st, a, d_dbg); }, chk})
     ABLV("copy of shipped (occ 3)", 0, 3, true);
     ABLV("copy of shipped (occ 2)", 0, 2, true);
+    ABLV("32-row kernel, no row max / m = 0 (occ 3)", lab::A_NOMAX, 3, true);
+    ABLV("32-row kernel, no row max / m = 0 (occ 4)", lab::A_NOMAX, 4, true);
     ABLV("abl: no softmax", lab::A_NOSM, 3, false);
     ABLV("abl: no barrier/DMA", lab::A_NOSYNC, 3, false);
     ABLV("abl: no LDS reads", lab::A_NOLDS, 3, false);
@@ -440,6 +447,23 @@ int main(int argc, char** argv) {
     ABLV("abl: no MFMA", lab::A_NOMFMA, 3, false);
     ABLV("abl: no softmax, no MFMA (LDS+DMA+barrier only)", lab::A_NOSM | lab::A_NOMFMA, 3, false);
     ABLV("abl: MFMA only (no softmax, sync, LDS)", lab::A_NOSM | lab::A_NOSYNC | lab::A_NOLDS, 3, false);
+    const int grid64 = ((pl.nqt + 1) / 2) * H * B;
+    vars.push_back({"attn64_kernel<2> (64 rows / wave, 256 / WG)", [&] { hipLaunchKernelGGL((attn64_kernel<2>), dim3(grid64), dim3(256), 0, st, a); }, true});
+    a.dbg = d_dbg;
+    a.wgflags = d_flags;
+    vars.push_back({"attn64 FAST (m = 0, no row max) + FIXUP launch", [&] {
+        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), 0, st, a); }, true});
+    static pf_attn_desc desc2;
+    desc2 = desc;
+    desc2.O = dout;
+    desc2.workspace = d_flags;
+    desc2.workspace_bytes = (long long)nwg_max * 4 * 4;
+    printf("pf_attention_which(desc + scratch) = %d\n", pf_attention_which(&desc2));
+    vars.push_back({"pf_attention_bf16 with scratch (library dispatch)", [&] { pf_attention_bf16(&desc2, st); }, true});
+    vars.push_back({"attn64 FAST alone", [&] { hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), 0, st, a); }, true});
+    vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), 0, st, a); }, true});
+    vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), 0, st, a); }, false});
     ABLV("stamped (occ 3)", lab::A_STAMP, 3, true);
 
     // reference output of the shipped kernel
@@ -448,41 +472,49 @@ int main(int argc, char** argv) {
     std::vector<unsigned short> href((size_t)B * L * d), hout((size_t)B * L * d);
     CK(hipMemcpy(href.data(), dref, href.size() * 2, hipMemcpyDeviceToHost));
 
-    // sampled rows of the shipped output vs fp32 on the host (harness sanity)
-    {
-        const int rows[] = {0, 39, 40, 127, 128, 367, 368, L / 2, L - 1};
-        double num = 0, den = 0;
-        for (int b = 0; b < B; ++b)
-            for (int row : rows)
-                for (int h = 0; h < H; h += 7) {
-                    const size_t ri = (size_t)b * L + row;
-                    const int lo = pl.a_lo[ri], hi_ = pl.a_hi[ri], bh = pl.b_hi[ri];
-                    std::vector<double> sc;
-                    std::vector<int> keys;
-                    double mx = -1e300;
-                    for (int k = 0; k < L; ++k) {
-                        const bool ok = k < pl.Lt ? (k >= lo && k < hi_) : (k < bh);
-                        if (!ok) continue;
-                        double s = 0;
-                        for (int e = 0; e < 64; ++e)
-                            s += (double)bf2f(hq[ri * ld + 2 * d + h * 64 + e]) * bf2f(hq[((size_t)b * L + k) * ld + h * 64 + e]);
-                        s *= 0.6931471805599453;
-                        sc.push_back(s); keys.push_back(k);
-                        mx = std::max(mx, s);
-                    }
-                    double sum = 0;
-                    for (double& s : sc) { s = exp(s - mx); sum += s; }
-                    for (int e = 0; e < 64; ++e) {
-                        double acc = 0;
-                        for (size_t i = 0; i < sc.size(); ++i) acc += sc[i] * bf2f(hq[((size_t)b * L + keys[i]) * ld + d + h * 64 + e]);
-                        acc /= sum;
-                        const double got = bf2f(href[ri * d + h * 64 + e]);
-                        num += (got - acc) * (got - acc);
-                        den += acc * acc;
-                    }
+    // sampled rows vs fp64 on the host: reference values computed once, every checked variant is compared with them
+    const std::vector<int> srows = {0, 39, 40, 127, 128, 367, 368, L / 2, L - 1};
+    std::vector<double> sref;       // [b][row][h in 0,7,14,21,28][64]
+    for (int b = 0; b < B; ++b)
+        for (int row : srows)
+            for (int h = 0; h < H; h += 7) {
+                const size_t ri = (size_t)b * L + row;
+                const int lo = pl.a_lo[ri], hi_ = pl.a_hi[ri], bh = pl.b_hi[ri];
+                std::vector<double> sc;
+                std::vector<int> keys;
+                double mx = -1e300;
+                for (int k = 0; k < L; ++k) {
+                    const bool ok = k < pl.Lt ? (k >= lo && k < hi_) : (k < bh);
+                    if (!ok) continue;
+                    double s_ = 0;
+                    for (int e = 0; e < 64; ++e)
+                        s_ += (double)bf2f(hq[ri * ld + 2 * d + h * 64 + e]) * bf2f(hq[((size_t)b * L + k) * ld + h * 64 + e]);
+                    s_ *= 0.6931471805599453;
+                    sc.push_back(s_); keys.push_back(k);
+                    mx = std::max(mx, s_);
                 }
-        printf("shipped kernel, sampled rows vs fp64 host reference: rel-L2 %.3e\n", sqrt(num / den));
-    }
+                double sum = 0;
+                for (double& s_ : sc) { s_ = exp(s_ - mx); sum += s_; }
+                for (int e = 0; e < 64; ++e) {
+                    double acc = 0;
+                    for (size_t i = 0; i < sc.size(); ++i) acc += sc[i] * bf2f(hq[((size_t)b * L + keys[i]) * ld + d + h * 64 + e]);
+                    sref.push_back(acc / sum);
+                }
+            }
+    auto vs_fp64 = [&](const std::vector<unsigned short>& out) {
+        double num = 0, den = 0;
+        size_t k = 0;
+        for (int b = 0; b < B; ++b)
+            for (int row : srows)
+                for (int h = 0; h < H; h += 7)
+                    for (int e = 0; e < 64; ++e) {
+                        const double got = bf2f(out[((size_t)b * L + row) * d + h * 64 + e]), want = sref[k++];
+                        num += (got - want) * (got - want);
+                        den += want * want;
+                    }
+        return sqrt(num / den);
+    };
+    printf("shipped kernel, sampled rows vs fp64 host reference: rel-L2 %.3e\n", vs_fp64(href));
 
     std::vector<std::vector<float>> ms(vars.size());
     hipEvent_t e0, e1;
@@ -514,10 +546,31 @@ int main(int argc, char** argv) {
                 const double x = bf2f(hout[i]), y = bf2f(href[i]);
                 num += (x - y) * (x - y); den += y * y; mxd = std::max(mxd, fabs(x - y));
             }
-            snprintf(chk, sizeof chk, "  vs shipped: rel-L2 %.2e max-abs %.2e", sqrt(num / den), mxd);
+            snprintf(chk, sizeof chk, "  vs shipped: rel-L2 %.2e max-abs %.2e | vs fp64 rows: %.2e", sqrt(num / den), mxd, vs_fp64(hout));
         }
         printf("%-52s med %.3f ms  min %.3f ms  %6.0f TF useful (med)%s\n", vars[v].name, med, mn, flops / med / 1e9, chk);
     }
+    for (int v64 = 2; v64 <= 3; ++v64) {
+        CK(hipMemset(d_dbg, 0, nwg_max * 4 * lab::NPH * 4));
+        if (v64 == 2) hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), 0, st, a);
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned> hd((size_t)grid64 * 4 * 8);
+        CK(hipMemcpy(hd.data(), d_dbg, hd.size() * 4, hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        for (size_t w = 0; w < (size_t)grid64 * 4; ++w)
+            for (int i = 0; i < 8; ++i) sum[i] += hd[w * 8 + i];
+        const char* nm[7] = {"S0: QK^T(A) (+ loop top)", "S1: QK^T(B) + [max(A) | exp(A) 0-2] + V reads", "S2: PV(A) + [exp(A) | exp(A) 3, exp(B) 0-1]", "tail: mask/max/check(B)",
+                             "wait vmcnt/lgkmcnt + barrier", "K / Q fragment reads issued", "S3: exp(B) + PV(B) + DMA"};
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) tot += sum[i];
+        printf("attn64 stamped%s: cycles per processed 64-key tile and wave (2 x 32 rows; the matrix pipe needs 1024):\n", v64 == 3 ? " FAST" : "");
+        for (int i = 0; i < 7; ++i) printf("   %-44s %8.1f  (%4.1f%%)\n", nm[i], sum[i] / sum[7], 100 * sum[i] / tot);
+        printf("   %-44s %8.1f\n", "total", tot / sum[7]);
+    }
+    CK(hipMemset(d_dbg, 0, nwg_max * 4 * lab::NPH * 4));
+    hipLaunchKernelGGL((lab::attn_abl_kernel<lab::A_STAMP, 3>), dim3(grid), dim3(256), 0, st, a, d_dbg);
+    CK(hipStreamSynchronize(st));
     // phase stamps of the last (stamped) variant
     {
         std::vector<unsigned> hd(nwg_max * 4 * lab::NPH);

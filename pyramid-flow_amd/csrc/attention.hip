@@ -37,6 +37,8 @@ struct AArgs {
     const int* a_lo; const int* a_hi; const int* b_hi;
     const int* tile_kv_end;
     float sc;   // softmax scale * log2(e)
+    unsigned* dbg;   // lab builds only (cycle stamps of attn64_kernel<.., 2>); nullptr in the library
+    int* wgflags;    // attn64 FAST / FIXUP pair: one int per wave (4 per workgroup), caller scratch
 };
 
 template <bool PRE, int ILP, int OCC>
@@ -278,6 +280,8 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AArgs p) {
     }
 }
 
+#include "attention_w64.h"
+
 // V [B, L, H*64] (row stride ldv) -> V^T [B, H, 64, Lp] with keys permuted inside each group of
 // 16 (bits 2 and 3 of the key index swapped) so the PV A-operand is one ds_read_b128 per lane.
 __global__ __launch_bounds__(256) void vtrans_kernel(const bf16_t* V, bf16_t* Vt, int ldv, long long sV,
@@ -333,6 +337,25 @@ __global__ __launch_bounds__(256) void vtrans_kernel(const bf16_t* V, bf16_t* Vt
 
 int pf_set_err(const char* m);
 
+// one int per wave of the 256-row kernel's grid (4 per workgroup)
+extern "C" long long pf_attention_workspace_bytes(int B, int H, int L) {
+    if (B <= 0 || H <= 0 || L <= 0) return 0;
+    return (long long)((L + 255) / 256) * H * B * 4 * (long long)sizeof(int);
+}
+
+// the 64-rows-per-wave pair needs caller scratch, pre-scaled q, 16-byte aligned output rows and at least two 256-row
+// workgroups per CU (below that the 128-row kernel keeps more of the chip busy)
+static bool use_w64(const pf_attn_desc* d) {
+    if (!d->q_prescaled || !d->workspace || d->L <= 0) return false;
+    const int nqt = (d->L + QB - 1) / QB;
+    const int qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
+    const long long grid64 = (long long)((nqt + 1) / 2 - qt0 / 2) * d->H * d->B;
+    return d->workspace_bytes >= pf_attention_workspace_bytes(d->B, d->H, d->L) && grid64 >= 512 && (d->ldo % 8) == 0 &&
+           (d->strideO % 8) == 0 && ((uintptr_t)d->O % 16) == 0 && ((uintptr_t)d->workspace % 4) == 0;
+}
+
+extern "C" int pf_attention_which(const pf_attn_desc* d) { return (d && use_w64(d)) ? 64 : 32; }
+
 extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     if (!d || !d->Q || !d->K || !d->Vt || !d->O) return pf_set_err("pf_attention_bf16: null operand");
     if (d->L <= 0 || d->B <= 0 || d->H <= 0) return pf_set_err("pf_attention_bf16: empty problem");
@@ -351,6 +374,17 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.prio = 1;              // s_setprio around the MFMA groups (measured best of {none, MFMA, softmax}: profiles/r01_attention_variants.log)
     a.qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
     if (a.qt0 >= a.nqt) return pf_set_err("pf_attention_bf16: q_row_begin beyond the sequence");
+    // Large pre-scaled problems with caller scratch: the 64-rows-per-wave kernel as a fast pass + a fix-up pass
+    // (attention_w64.h; +8...13 % over the kernel below from L = 3 008 up: profiles/r03_attention_w64_fast_fixup.log).
+    if (use_w64(d)) {
+        const int grid64 = ((a.nqt + 1) / 2 - a.qt0 / 2) * a.H * a.B;
+        a.wgflags = (int*)d->workspace;
+        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), 0, stream, a);
+        hipError_t e64 = hipGetLastError();
+        if (e64 != hipSuccess) return pf_set_err(hipGetErrorString(e64));
+        return 0;
+    }
     const int grid = (a.nqt - a.qt0) * a.H * a.B;
     // one max chain, three waves per SIMD: 2 / 4 chains and 2 waves per SIMD measured within 2 % (same log)
     if (!d->q_prescaled) hipLaunchKernelGGL((attn_kernel<false, 1, 3>), dim3(grid), dim3(256), 0, stream, a);

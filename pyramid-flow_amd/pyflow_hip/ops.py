@@ -96,10 +96,28 @@ def gemm_set_policy(force):
 LOG2E = 1.4426950408889634
 
 
+_ATTN_WS = {}          # device -> (int32 scratch of pf_attention_bf16's two-launch form, retired buffers kept alive)
+
+
+def _attention_workspace(device, nbytes):
+    """per-device scratch for the flag words of the fast / fix-up attention pair.  Grow-only; a replaced buffer stays
+    referenced because recorded launch lists / captured graphs may still point at it.  Attention launches of one device
+    are stream-ordered on the compute stream, so one buffer serves them all."""
+    ent = _ATTN_WS.get(device)
+    if ent is None or ent[0].numel() * 4 < nbytes:
+        t = torch.zeros(max(nbytes // 4, 1 << 16), dtype=torch.int32, device=device)
+        _ATTN_WS[device] = ent = (t, (ent[1] + [ent[0]]) if ent else [])
+    return ent[0]
+
+
 def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale, q_prescaled=False,
               head_stride_qk=0, ldo=None, o_bstride=None, q_row_begin=0):
     lib = L.load()
     d = AttnDesc()
+    if q_prescaled:
+        need = int(lib.pf_attention_workspace_bytes(C.c_int(B), C.c_int(H), C.c_int(Lseq)))
+        ws = _attention_workspace(Q.device, need)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.Q = Q.data_ptr() + 2 * q_off
     d.K = K.data_ptr() + 2 * k_off
     d.Vt = Vt.data_ptr()

@@ -1,0 +1,144 @@
+"""The 64-rows-per-wave attention pair (csrc/attention_w64.h): a fast pass without any running row maximum + a fix-up
+pass with it that recomputes the workgroups the fast pass flagged.  Replaces F.scaled_dot_product_attention with the
+[B,1,L,L] mask (flux_block.py:361-365, modeling_pyramid_flux.py:318-350) exactly like the 32-row kernel; tolerance of
+one attention op: rel-L2 <= 1e-2 against an fp32 restatement with the dense mask.
+  * benchmark-like scores (+-10 in base-2 units): every row against the dense reference, the pair is what runs,
+  * scores far outside the window the fast pass is exact in (|s| up to ~400: exp2 overflows / every key underflows):
+    the fix-up pass must deliver the right rows,
+  * the last-block form (q_row_begin) and the sequence-parallel layout (head stride 192, strided output)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D, H, LT = 1920, 30, 128
+CLIPS = [(3, 24, 40), (1, 24, 40), (1, 48, 80), (1, 48, 80)]          # unit 5, stage 1: L = 3 008
+
+
+def _mask():
+    m = torch.zeros(2, LT, dtype=torch.long)
+    m[0, :40] = 1
+    m[1, :96] = 1
+    return m
+
+
+def _reference(qkv, plan, B, L, rows=None):
+    """fp32 softmax with the dense mask rows; q is pre-scaled (scores are base-2 exponents)"""
+    rows = list(range(L)) if rows is None else rows
+    dm = torch.from_numpy(plan.dense_mask()[:, rows]).to(DEV)
+    q = qkv[:, rows, 2 * D:].float().view(B, len(rows), H, 64).transpose(1, 2)
+    k = qkv[..., :D].float().view(B, L, H, 64).transpose(1, 2)
+    v = qkv[..., D:2 * D].float().view(B, L, H, 64).transpose(1, 2)
+    out = torch.empty(B, len(rows), D, device=DEV)
+    for b in range(B):          # per batch entry: [H, R, L] fp32 scores
+        s = torch.einsum("hrd,hld->hrl", q[b], k[b]) * 0.6931471805599453
+        s = s.masked_fill(~dm[b][None], float("-inf"))
+        out[b] = torch.einsum("hrl,hld->hrd", torch.softmax(s, -1), v[b]).transpose(0, 1).reshape(len(rows), D)
+    return out
+
+
+def _run(qkv, plan, B, L, Lp, q_row_begin=0):
+    from pyflow_hip import ops
+    vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device=DEV)
+    ops.v_transpose(qkv, vT, D, 3 * D, L * 3 * D, B, H, L, Lp)
+    out = torch.zeros(B, L, D, dtype=torch.bfloat16, device=DEV)
+    ops.attention(qkv, qkv, vT, out, 2 * D, 0, 0, 3 * D, L * 3 * D, B, H, L, Lp, LT, plan, 0.125, q_prescaled=True,
+                  ldo=D, o_bstride=L * D, q_row_begin=q_row_begin)
+    return out
+
+
+def _which(plan, B, L, Lp, prescaled=True):
+    from pyflow_hip import lib, ops
+    d = lib.AttnDesc()
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 16)
+    d.Q = d.K = d.Vt = d.O = ws.data_ptr()
+    d.ldq = d.ldk = 3 * D
+    d.ldo = D
+    d.strideO = L * D
+    d.B, d.H, d.L, d.Lp, d.Lt = B, H, L, Lp, LT
+    d.q_prescaled = int(prescaled)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    return lib.load().pf_attention_which(C.byref(d))
+
+
+def test_pair_runs_for_the_benchmark_shapes_and_matches_dense_reference():
+    from pyflow_hip import ops
+    from pyflow_hip.plan import SequencePlan
+    B = 2
+    plan = SequencePlan(CLIPS, _mask(), [16, 24, 24], DEV)
+    L, Lp = plan.L, plan.Lp
+    assert L == 3008 and _which(plan, B, L, Lp) == 64 and _which(plan, B, L, Lp, prescaled=False) == 32
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(B, L, 3 * D, generator=g, device=DEV)
+    qkv[..., 2 * D:] *= 0.125 * ops.LOG2E
+    qkv = qkv.to(torch.bfloat16)
+    ref = _reference(qkv, plan, B, L)
+    out = _run(qkv, plan, B, L, Lp)
+    err = rel_l2(out.float().cpu(), ref.cpu())
+    print(f"attention pair, L = 3008, every row vs dense fp32 reference: rel-L2 {err:.3e}")
+    assert err < 1e-2
+    # the 32-row kernel on the same input (no scratch offered): same tolerance, and the two agree closely
+    from pyflow_hip import lib
+    vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device=DEV)
+    ops.v_transpose(qkv, vT, D, 3 * D, L * 3 * D, B, H, L, Lp)
+    out32 = torch.zeros_like(out)
+    d = lib.AttnDesc()
+    d.Q, d.K, d.Vt, d.O = qkv.data_ptr() + 2 * 2 * D, qkv.data_ptr(), vT.data_ptr(), out32.data_ptr()
+    d.ldq = d.ldk = 3 * D
+    d.ldo = D
+    d.strideQ = d.strideK = L * 3 * D
+    d.strideO = L * D
+    d.strideVt_b, d.strideVt_h = H * 64 * Lp, 64 * Lp
+    d.B, d.H, d.L, d.Lp, d.Lt = B, H, L, Lp, LT
+    d.a_lo, d.a_hi, d.b_hi = plan.a_lo.data_ptr(), plan.a_hi.data_ptr(), plan.b_hi.data_ptr()
+    d.tile_kv_end = plan.tile_kv_end.data_ptr()
+    d.scale, d.q_prescaled = 0.125, 1
+    lib.check(lib.load().pf_attention_bf16(C.byref(d), lib.stream()))
+    assert rel_l2(out32.float().cpu(), ref.cpu()) < 1e-2
+    assert rel_l2(out.float().cpu(), out32.float().cpu()) < 5e-3
+    # last-block form: rows below q_row_begin are not needed.  The remaining rows are too few workgroups for the pair
+    # here (4 x 60 of 256 rows), so the 32-row kernel serves them: identical to its full run, close to the pair's rows
+    r0 = L - plan.n_cur
+    tail = _run(qkv, plan, B, L, Lp, q_row_begin=r0)
+    assert torch.equal(tail[:, r0:], out32[:, r0:])
+    assert rel_l2(tail[:, r0:].float().cpu(), out[:, r0:].float().cpu()) < 5e-3
+
+
+@pytest.mark.parametrize("case", ["overflow", "underflow", "mixed"])
+def test_fix_up_pass_recomputes_rows_outside_the_fast_window(case):
+    """scores far beyond what exp2 represents without a running maximum: the fast pass must flag those rows and the
+    fix-up pass (running maximum, deferred rescale) must produce them; rows inside the window are untouched by it"""
+    from pyflow_hip import ops
+    from pyflow_hip.plan import SequencePlan
+    B = 2
+    plan = SequencePlan(CLIPS, _mask(), [16, 24, 24], DEV)
+    L, Lp = plan.L, plan.Lp
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(B, L, 3 * D, generator=g, device=DEV)
+    qkv[..., 2 * D:] *= 0.125 * ops.LOG2E
+    q = qkv[..., 2 * D:]
+    k = qkv[..., :D]
+    if case in ("overflow", "mixed"):
+        # rows 700..899 (frames 2 / 3): q shifted, 40 keys of frame 3 shifted the same way: scores of ~ +380 where visible,
+        # +-100 elsewhere in those rows
+        q[:, 700:900] += 2.0
+        k[:, 1000:1040] += 3.0
+    if case in ("underflow", "mixed"):
+        # rows 2000..2199: every score ~ -250 (q anti-aligned with a component all keys share)
+        q[:, 2000:2200] -= 3.0
+        k += 1.3
+    qkv = qkv.to(torch.bfloat16)
+    ref = _reference(qkv, plan, B, L)
+    assert torch.isfinite(ref).all()
+    sc = torch.einsum("bld,bmd->blm", qkv[:, :, 2 * D:2 * D + 64].float(), qkv[:, :, :64].float())
+    print(f"{case}: head-0 score range {sc.min().item():.0f} .. {sc.max().item():.0f} (base-2 exponents)")
+    assert sc.abs().max() > 150
+    out = _run(qkv, plan, B, L, Lp)
+    assert torch.isfinite(out.float()).all()
+    err = rel_l2(out.float().cpu(), ref.cpu())
+    print(f"{case}: attention pair vs dense fp32 reference rel-L2 {err:.3e}")
+    assert err < 1e-2
