@@ -57,6 +57,7 @@ def exchange_unique_id(rank, world, path=None):
 class NativeComm:
     native = True
     backend = "pf_comm"
+    recordable = True          # all_to_all / wait have launch-list entries (pf_cmdlist_all_to_all_v / pf_cmdlist_comm_wait)
 
     def __init__(self, rank, world, unique_id):
         lib = L.load()

@@ -14,6 +14,23 @@ the reference lacks:
   * uneven head map (H = 30: 15|15, 8|8|7|7, 4x6|3|3) through all_to_all_single split sizes;
   * the velocity tokens of the current frame (last t*h*w rows) are summed across ranks into a replicated fp32
     buffer (C14) -- every rank then performs the identical Euler update (replaces the per-step broadcast C2).
+
+Round 3 -- production shape of the per-forward sequence:
+  * BOTH exchanges are asynchronous (`trainer_misc/communicate.py:7-66` is blocking): in the single-stream blocks the MLP
+    branch (proj_mlp + GELU, flux_block.py:921-922, independent of the attention) is split 2 : 1 -- two thirds of its
+    columns are computed while the K|V|Q exchange (3 d columns) is in flight, the last third while the attention-output
+    exchange (d columns) is; in the double-stream blocks nothing is independent of the exchanges (the text rows' K|V|Q are
+    part of what is exchanged);
+  * the blocks + head of a (unit, stage) are RECORDED into a launch list (pyflow_hip/cmdlist.py) when the communicator
+    can be recorded -- the C-ABI communicator (`NativeComm`: pf_cmdlist_all_to_all_v / pf_cmdlist_comm_wait entries) or a
+    single rank (`LocalComm`) -- and replayed by one C call per forward; torch.distributed collectives cannot be recorded
+    (gloo tests, `--comm torch`): those run the same sequence eagerly;
+  * the LAST block computes the attention, the MLP branch and the out-projection only for the current frame's rows
+    (split_output keeps [-n_cur:], modeling_pyramid_flux.py:380): every rank saves the attention rows below them, the
+    ranks that own no such row skip their MLP / out-projection launches.
+Text rows stay with the ranks that own them in the merged order (rank 0 at P <= 8 for 128 text rows): their skinny GEMMs
+stream the text-stream weights once and cost 0.26 ms per forward when run alone -- splitting them over
+ranks would make EVERY rank stream those weights and save nothing.
 """
 import torch
 
@@ -30,6 +47,7 @@ class FluxEngineSP(FluxEngine):
         super().__init__(state_dict, cfg, device)
         self.comm = comm if comm is not None else LocalComm()
         self._layouts = {}
+        self.launch_mode = "list"          # "list": record + replay when the communicator allows it; "eager": never
 
     def layout(self, plan):
         key = (plan.L, plan.Lt)
@@ -39,57 +57,62 @@ class FluxEngineSP(FluxEngine):
             self._layouts[key] = lay
         return lay
 
-    # ---- the two exchanges -------------------------------------------------------------------------------------
-    def _exchange_qkv(self, lay, big, ld, B, send, recv, async_op=False):
-        """big[B][nloc][ld] (first 3d columns head-major) -> recv[L][B][my_cols]; returns a wait handle or None"""
+    # ---- the two exchanges (both return a wait handle or None) ----------------------------------------------------
+    def _exchange_qkv(self, lay, big, ld, B, send, recv):
+        """big[B][nloc][ld] (first 3d columns head-major) -> recv[L][B][my_cols]"""
         nloc = lay.nloc
         s_spl, r_spl = lay.a2a1_splits(B)
         if nloc:
             parts = [p for p in range(lay.P) if lay.heads[p]]
             ops.sp_relayout(big, send, nloc, B, ld, nloc * ld, [lay.head0[p] * lay.HEAD_COLS for p in parts],
                             [lay.heads[p] * lay.HEAD_COLS for p in parts], [sum(s_spl[:p]) for p in parts], True)
-        return self.comm.all_to_all(recv, send, r_spl, s_spl, async_op=async_op)
+        return self.comm.all_to_all(recv, send, r_spl, s_spl, async_op=True)
 
-    def _exchange_out(self, lay, obuf, B, recv, dst, ld_dst, col0):
-        """obuf[L][B][my_heads*64] -> dst[B][nloc][ld_dst] columns col0 .. col0 + d (all heads, head order)"""
+    def _exchange_out_start(self, lay, obuf, B, recv):
         s_spl, r_spl = lay.a2a2_splits(B)
-        self.comm.all_to_all(recv, obuf, r_spl, s_spl)
+        return self.comm.all_to_all(recv, obuf, r_spl, s_spl, async_op=True)
+
+    def _exchange_out_finish(self, lay, h, B, recv, dst, ld_dst, col0):
+        """recv[src][row][b][src's heads x 64] -> dst[B][nloc][ld_dst] columns col0 .. col0 + d (all heads, head order)"""
+        if h is not None:
+            h.wait()
+        _, r_spl = lay.a2a2_splits(B)
         nloc = lay.nloc
         if nloc:
             parts = [p for p in range(lay.P) if lay.heads[p]]
             ops.sp_relayout(dst, recv, nloc, B, ld_dst, nloc * ld_dst, [col0 + lay.head0[p] * 64 for p in parts],
                             [lay.heads[p] * 64 for p in parts], [sum(r_spl[:p]) for p in parts], False)
 
-    # ---- forward ----------------------------------------------------------------------------------------------
-    def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):
+    # ---- buffers of one (plan, rank) -------------------------------------------------------------------------------
+    def _sp_state(self, plan):
         w = self.w
-        d, H = w.d, w.H
-        B, Lt, L, L_img, Lp = plan.B, plan.Lt, plan.L, plan.L_img, plan.Lp
+        d = w.d
+        B, L, L_img, Lp = plan.B, plan.L, plan.L_img, plan.Lp
         lay = self.layout(plan)
-        nloc, n_txt, n_img = lay.nloc, lay.n_txt, lay.n_img
-        mh, mc = lay.my_heads, lay.my_cols
-        ctx = ctx if ctx is not None else self._ctx
-        mod, _ = self.conditioning(timesteps, pooled)
-        nm = w.n_mod
+        nloc, mh, mc = lay.nloc, lay.my_heads, lay.my_cols
         bf = torch.bfloat16
-        hidden = self._buf("sp_hidden", B * nloc * d, bf)
-        xn = self._buf("sp_xn", B * nloc * d, bf)
-        big = self._buf("sp_big", B * nloc * 7 * d, bf)
-        send1 = self._buf("sp_send1", B * nloc * 3 * d, bf)
-        recv1 = self._buf("sp_recv1", L * B * max(mc, 1), bf)
-        obuf = self._buf("sp_obuf", L * B * max(mh, 1) * 64, bf)
-        recv2 = self._buf("sp_recv2", B * nloc * d, bf)
-        vT = self._buf("vT", B * max(mh, 1) * 64 * Lp, bf)
-        # scratch of the text rows' skinny GEMMs: same K split as the single-process engine (one 128-row tile per prompt
-        # either way), hence the same fp32 summation order and bit-identical text rows
-        ws_txt = self._buf("splitk_txt", 8 << 20, torch.float32)
-        tok = self._buf("tok", B * L_img * w.in_ch, bf)
-        Ld, L3, L4, L7 = nloc * d, nloc * 3 * d, nloc * 4 * d, nloc * 7 * d
-        mlp_base = B * L3
-        scale = 64 ** -0.5
-        qs = scale * ops.LOG2E
+        n_cur = plan.n_cur
+        npad = w.proj_w.shape[0]
+        return dict(
+            lay=lay,
+            hidden=self._buf("sp_hidden", B * nloc * d, bf), xn=self._buf("sp_xn", B * nloc * d, bf),
+            big=self._buf("sp_big", B * nloc * 7 * d, bf), send1=self._buf("sp_send1", B * nloc * 3 * d, bf),
+            recv1=self._buf("sp_recv1", L * B * max(mc, 1), bf), obuf=self._buf("sp_obuf", L * B * max(mh, 1) * 64, bf),
+            recv2=self._buf("sp_recv2", B * nloc * d, bf), vT=self._buf("vT", B * max(mh, 1) * 64 * Lp, bf),
+            # scratch of the text rows' skinny GEMMs: same K split as the single-process engine (one 128-row tile per
+            # prompt either way), hence the same fp32 summation order and bit-identical text rows
+            ws_txt=self._buf("splitk_txt", 8 << 20, torch.float32),
+            tok=self._buf("tok", B * L_img * w.in_ch, bf),
+            vtok=self._buf("vtok", B * n_cur * npad, torch.float32))
 
-        # ---- embed (local rows only): text rows <- cached context, image rows <- x_embedder(patchify)
+    def _embed_local(self, plan, clips, ctx, shared_clips, st):
+        """local rows only: text rows <- cached context, image rows <- x_embedder(patchify)"""
+        w = self.w
+        d = w.d
+        B, Lt, L_img = plan.B, plan.Lt, plan.L_img
+        lay, hidden, tok = st["lay"], st["hidden"], st["tok"]
+        n_txt, n_img = lay.n_txt, lay.n_img
+        Ld = lay.nloc * d
         if n_txt:
             ops.copy_rows(ctx, hidden, n_txt, d, d, d, Lt * d, Ld, B, src_off=lay.r0 * d)
         row = 0
@@ -109,14 +132,34 @@ class FluxEngineSP(FluxEngine):
             ops.gemm(tok, w.x_w, hidden, n_img, d, w.in_ch, w.in_ch, w.in_ch, d, bias=w.x_b, batch=B,
                      strideA=L_img * w.in_ch, strideC=Ld, a_off=lay.img0 * w.in_ch, c_off=n_txt * d)
 
+    # ---- blocks + head over the local rows (recordable) -----------------------------------------------------------
+    def _run_sp_blocks(self, plan, mod, st, debug=None):
+        w = self.w
+        d = w.d
+        B, Lt, L, Lp = plan.B, plan.Lt, plan.L, plan.Lp
+        lay = st["lay"]
+        nloc, n_txt, n_img = lay.nloc, lay.n_txt, lay.n_img
+        mh, mc = lay.my_heads, lay.my_cols
+        hidden, xn, big, send1, recv1, obuf, recv2, vT, ws_txt, vtok = (st[k] for k in (
+            "hidden", "xn", "big", "send1", "recv1", "obuf", "recv2", "vT", "ws_txt", "vtok"))
+        nm = w.n_mod
+        Ld, L3, L4, L7 = nloc * d, nloc * 3 * d, nloc * 4 * d, nloc * 7 * d
+        mlp_base = B * L3
+        scale = 64 ** -0.5
+        qs = scale * ops.LOG2E
+        n_cur = plan.n_cur
+        r_cur = L - n_cur                                   # first row of the current frame (global)
+        la0 = min(max(r_cur - lay.r0, 0), nloc)             # first LOCAL row the last block has to produce
+        dead_ok = self.skip_dead_rows and n_cur < L
+
         def ln(rows, x_off, sh, sc):
             if rows:
                 ops.ln_modulate(hidden, xn, (mod, sh), (mod, sc), d, B, rows, Ld, Ld, d, d, nm, x_off=x_off, y_off=x_off)
 
-        def attend(ld, overlap=None):
+        def attend(ld, norms, overlap=None, q_row_begin=0):
             """big (first 3d columns, head-major) -> obuf = attention output of my heads for all rows.
             `overlap`: work that does not depend on the exchange, queued while the all-to-all is in flight."""
-            h = self._exchange_qkv(lay, big, ld, B, send1, recv1, async_op=overlap is not None)
+            h = self._exchange_qkv(lay, big, ld, B, send1, recv1)
             if overlap is not None:
                 overlap()
             if h is not None:
@@ -126,11 +169,17 @@ class FluxEngineSP(FluxEngine):
                                  head_stride=lay.HEAD_COLS, eps=w.qk_eps)
                 ops.v_transpose(recv1, vT, 64, B * mc, mc, B, mh, L, Lp, head_stride=lay.HEAD_COLS)
                 ops.attention(recv1, recv1, vT, obuf, 128, 0, 0, B * mc, mc, B, mh, L, Lp, Lt, plan, scale,
-                              q_prescaled=True, head_stride_qk=lay.HEAD_COLS, ldo=B * mh * 64, o_bstride=mh * 64)
+                              q_prescaled=True, head_stride_qk=lay.HEAD_COLS, ldo=B * mh * 64, o_bstride=mh * 64,
+                              q_row_begin=q_row_begin)
 
-        for blk in w.dbl:
+        n_dbl = len(w.dbl)
+        for bi, blk in enumerate(w.dbl):
             mb = blk["mod"]
             pre_only = blk["pre_only"]         # last MMDiT block: the text stream only feeds the attention
+            # last block of a model without single blocks: only the current frame's rows go on
+            tail = dead_ok and pre_only and not w.sgl and bi == n_dbl - 1
+            i0 = max(la0, n_txt) if tail else n_txt          # first local image row computed in full after the attention
+            n_act = nloc - i0
             ln(n_img, n_txt * d, mb + 0, mb + d)
             if pre_only:
                 ln(n_txt, 0, mb + 7 * d, mb + 6 * d)      # AdaLayerNormContinuous: (scale, shift)
@@ -143,26 +192,27 @@ class FluxEngineSP(FluxEngine):
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
                          strideA=Ld, strideC=L3, workspace=ws_txt)
             norms = (blk["norm_q"], blk["norm_k"], blk["norm_added_q"], blk["norm_added_k"])
-            attend(3 * d)
-            self._exchange_out(lay, obuf, B, recv2, big, 3 * d, 0)          # attention rows -> big[..., 0:d]
-            if n_img:
-                ops.gemm(big, blk["o_img"][0], hidden, n_img, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
+            attend(3 * d, norms, q_row_begin=r_cur if tail else 0)
+            h2 = self._exchange_out_start(lay, obuf, B, recv2)
+            self._exchange_out_finish(lay, h2, B, recv2, big, 3 * d, 0)          # attention rows -> big[..., 0:d]
+            if n_act > 0:
+                ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=n_txt * 3 * d, c_off=n_txt * d, r_off=n_txt * d)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d)
             if n_txt and not pre_only:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, workspace=ws_txt)
-            ln(n_img, n_txt * d, mb + 3 * d, mb + 4 * d)
+            ln(n_act if n_act > 0 else 0, i0 * d, mb + 3 * d, mb + 4 * d)
             if not pre_only:
                 ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
-            if n_img:
-                ops.gemm(xn, blk["ff1_img"][0], big, n_img, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
-                         strideA=Ld, strideC=L4, gelu_from=0, a_off=n_txt * d, c_off=mlp_base + n_txt * 4 * d)
-                ops.gemm(big, blk["ff2_img"][0], hidden, n_img, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
+            if n_act > 0:
+                ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
+                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d)
+                ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                          res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + n_txt * 4 * d, c_off=n_txt * d,
-                         r_off=n_txt * d)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + i0 * 4 * d, c_off=i0 * d,
+                         r_off=i0 * d)
             if n_txt and not pre_only:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
@@ -170,42 +220,104 @@ class FluxEngineSP(FluxEngine):
                          res=hidden, gate=mod, gate_off=mb + 11 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base, workspace=ws_txt)
 
-        for blk in w.sgl:
+        # MLP branch of a single block in two column groups (2 : 1): the first under the K|V|Q exchange, the second under
+        # the attention-output exchange.  256-column multiples so that both launches take the same tile kernels.
+        n1 = (4 * d * 2 // 3) // 256 * 256
+        n_sgl = len(w.sgl)
+        for bi, blk in enumerate(w.sgl):
             mb = blk["mod"]
+            last = dead_ok and bi == n_sgl - 1
+            i0 = la0 if last else 0                        # first local row whose MLP branch / out-projection is needed
+            n_act = nloc - i0
             ln(nloc, 0, mb, mb + d)
-            # K|V|Q first, then the MLP branch (proj_mlp + GELU, flux_block.py:921-922) while the qkv all-to-all flies
+            # K|V|Q first, then the MLP branch (proj_mlp + GELU, flux_block.py:921-922) while the exchanges fly
             if nloc:
                 ops.gemm(xn, blk["kvqm"][0], big, nloc, 3 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
                          strideC=L7)
 
-            def mlp_branch(blk=blk):
-                if nloc:
-                    ops.gemm(xn, blk["kvqm"][0], big, nloc, 4 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B,
-                             strideA=Ld, strideC=L7, gelu_from=0, w_off=3 * d * d, c_off=3 * d, bias_off=3 * d)
+            def mlp_cols(c0, nc, blk=blk, i0=i0, n_act=n_act):
+                if n_act > 0 and nc > 0:
+                    ops.gemm(xn, blk["kvqm"][0], big, n_act, nc, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B,
+                             strideA=Ld, strideC=L7, gelu_from=0, a_off=i0 * d, w_off=(3 * d + c0) * d,
+                             c_off=i0 * 7 * d + 3 * d + c0, bias_off=3 * d + c0)
             norms = (blk["norm_q"], blk["norm_k"], None, None)
-            attend(7 * d, overlap=mlp_branch)
-            self._exchange_out(lay, obuf, B, recv2, big, 7 * d, 2 * d)      # [attn | mlp] = big[..., 2d:7d)
-            if nloc:
-                ops.gemm(big, blk["out"][0], hidden, nloc, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
+            attend(7 * d, norms, overlap=lambda: mlp_cols(0, n1), q_row_begin=r_cur if last else 0)
+            h2 = self._exchange_out_start(lay, obuf, B, recv2)
+            mlp_cols(n1, 4 * d - n1)
+            self._exchange_out_finish(lay, h2, B, recv2, big, 7 * d, 2 * d)      # [attn | mlp] = big[..., 2d:7d)
+            if n_act > 0:
+                ops.gemm(big, blk["out"][0], hidden, n_act, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=2 * d)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 7 * d + 2 * d, c_off=i0 * d, r_off=i0 * d)
         if debug is not None:
             debug["hidden_final_local"] = hidden[:B * nloc * d].view(B, nloc, d).clone()
 
-        # ---- norm_out + proj_out on my part of the current frame's rows; sum the disjoint parts across ranks
-        n_cur = plan.n_cur
+        # ---- norm_out + proj_out on my part of the current frame's rows (summed over the ranks by the caller)
         npad = w.proj_w.shape[0]
-        vtok = self._buf("vtok", B * n_cur * npad, torch.float32)
-        lo = max(lay.r0, L - n_cur)
+        lo = max(lay.r0, r_cur)
         cnt = lay.r1 - lo
-        if self.comm.world > 1:
-            vtok[:B * n_cur * npad].zero_()
         if cnt > 0:
             fo = (lo - lay.r0) * d
             mf = w.mod_final
             ops.ln_modulate(hidden, xn, (mod, mf + d), (mod, mf), d, B, cnt, Ld, Ld, d, d, nm, x_off=fo, y_off=fo)
             ops.gemm(xn, w.proj_w, vtok, cnt, npad, d, d, d, npad, bias=w.proj_b, batch=B, strideA=Ld,
-                     strideC=n_cur * npad, flags=GEMM_OUT_F32, a_off=fo, c_off=(lo - (L - n_cur)) * npad)
+                     strideC=n_cur * npad, flags=GEMM_OUT_F32, a_off=fo, c_off=(lo - r_cur) * npad)
+
+    def _run_sp_list(self, plan, mod, st):
+        """the blocks + head of this (unit, stage) through a launch list recorded once: the kernels, the relayouts and --
+        with the C-ABI communicator -- the exchanges and their waits are re-issued by ONE C call per forward"""
+        from .cmdlist import CommandList, recording
+        n_mod = plan.B * self.w.n_mod
+        for _ in range(2):
+            ms = self._buf("mod_fixed", n_mod, torch.float32)
+            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm))
+            ent = getattr(plan, "_sp_list", None)
+            if ent is not None and ent[0] == key:
+                break
+            cl = CommandList()
+            with recording(cl):
+                self._run_sp_blocks(plan, ms, st)
+            if key[1] != self._ws_gen:           # a buffer was (re)allocated while recording: record again
+                st = self._sp_state(plan)
+                continue
+            plan._sp_list = ent = (key, cl)
+            if getattr(self, "_listed_plans", None) is None:
+                import weakref
+                self._listed_plans = weakref.WeakSet()
+            self._listed_plans.add(plan)
+            break
+        else:
+            raise RuntimeError("launch list: the workspace did not settle")
+        self._ws["mod_fixed"][:n_mod].copy_(mod.reshape(-1)[:n_mod])
+        ent[1].run(torch.cuda.current_stream())
+
+    def _buf(self, name, numel, dtype):
+        gen = self._ws_gen
+        t = super()._buf(name, numel, dtype)
+        if gen != self._ws_gen:                  # stale pointers in every recorded sequence-parallel list as well
+            for p_ in list(getattr(self, "_listed_plans", None) or ()):
+                p_.__dict__.pop("_sp_list", None)
+        return t
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):
+        w = self.w
+        B = plan.B
+        ctx = ctx if ctx is not None else self._ctx
+        mod, _ = self.conditioning(timesteps, pooled)
+        st = self._sp_state(plan)
+        self._embed_local(plan, clips, ctx, shared_clips, st)
+        n_cur = plan.n_cur
+        npad = w.proj_w.shape[0]
+        vtok = st["vtok"]
+        if self.comm.world > 1:
+            vtok[:B * n_cur * npad].zero_()
+        recordable = (self.launch_mode != "eager" and getattr(self.comm, "recordable", False) and debug is None
+                      and not ops.PROFILER.enabled)
+        if recordable:
+            self._run_sp_list(plan, mod, st)
+        else:
+            self._run_sp_blocks(plan, mod, st, debug)
         if self.comm.world > 1:
             self.comm.all_reduce(vtok[:B * n_cur * npad])
         return vtok[:B * n_cur * npad].view(B, n_cur, npad)

@@ -66,9 +66,18 @@ class SPLayout:
 class LocalComm:
     """world of one: the exchanges are plain device copies (used to test the SP code path on a single GPU)."""
     rank, world = 0, 1
+    recordable = True          # its one collective is a recordable copy kernel (launch lists, pyflow_hip/cmdlist.py)
 
     def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
-        recv[:sum(send_splits)].copy_(send[:sum(send_splits)])
+        n = sum(send_splits)
+        if n == 0:
+            return None
+        if send.is_cuda and send.dtype == torch.bfloat16 and n % 8 == 0:
+            from . import ops
+            ops.copy_rows(send, recv, 1, n, n, n, 0, 0, 1)          # pf_copy_rows: recordable, stream-ordered
+        else:
+            recv[:n].copy_(send[:n])
+        return None
 
     def all_reduce(self, t):
         return t
@@ -101,6 +110,7 @@ class SPComm:
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.native = self.backend == "nccl"          # RCCL: device-side all_to_all_single with split sizes
+        self.recordable = False                       # torch.distributed calls cannot be recorded into a launch list
 
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
