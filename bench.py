@@ -267,6 +267,9 @@ def main():
                     help="run the double blocks' text stream on the compute stream instead of the side stream (A/B switch)")
     ap.add_argument("--launch-mode", default="graph", choices=["eager", "list", "graph"],
                     help="how the DiT's launches reach the device (pyflow_hip/cmdlist.py); default = the engine's default")
+    ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
+                    help="N > 1, sp: communicator -- auto = the C-ABI RCCL communicator (pf_comm_*) when its self-test passes on "
+                         "every rank, else torch.distributed")
     ap.add_argument("--parallelism", default="sp", choices=["sp", "replicas"],
                     help="N > 1: sp = one video across all GPUs (default), replicas = one video per GPU")
     args = ap.parse_args()
@@ -291,22 +294,42 @@ def main():
         dist.init_process_group(os.environ.get("PF_DIST_BACKEND", "nccl"))
         if use_sp:      # must exist before the model is built (reference contract, inference_multigpu.py:34-39)
             from pyflow_hip import sp as sp_mod
-            comm = sp_mod.init_sequence_parallel_group(sp_group_size=world)
-            comm_used = comm
-            # every collective of the path once, with known values, before any model is built; if a rank cannot run it
-            # all ranks agree to fall back to independent replicas (reported as such in the JSON line)
-            ok = 1
-            try:
-                comm.selftest(device)
-            except Exception as e:          # noqa: BLE001
-                print(f"[bench] rank {rank}: sequence-parallel self-test failed ({e!r}); falling back to replicas",
+
+            def agreed(ok_local):
+                """True iff EVERY rank succeeded (control plane: the default process group)"""
+                f = torch.tensor([0.0 if ok_local else 1.0], dtype=torch.float32,
+                                 device=device if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(f)
+                return float(f.item()) == 0.0
+
+            def try_comm(native):
+                """build the communicator and run every collective of the path once with known values"""
+                try:
+                    c = sp_mod.init_sequence_parallel_group(sp_group_size=world, native=native)
+                    c.selftest(device)
+                    return c, True
+                except Exception as e:          # noqa: BLE001
+                    print(f"[bench] rank {rank}: sequence-parallel self-test ({'pf_comm' if native else 'torch.distributed'}) "
+                          f"failed: {e!r}", file=sys.stderr, flush=True)
+                    return None, False
+            comm = None
+            # the C-ABI communicator first (its exchanges are launch-list entries: one C call per forward instead of ~350
+            # Python launches + ~50 c10d calls); needs RCCL, i.e. one GPU per rank
+            if args.comm in ("auto", "native") and dist.get_backend() == "nccl":
+                comm, ok = try_comm(True)
+                if not agreed(ok):
+                    comm = None
+                    sp_mod._SP = None
+            if comm is None and args.comm != "native":
+                comm, ok = try_comm(False)
+                if not agreed(ok):
+                    comm = None
+            if comm is None:        # all ranks agree: independent replicas instead (reported as such in the JSON line)
+                print(f"[bench] rank {rank}: no working sequence-parallel communicator; falling back to replicas",
                       file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([1.0 - ok], dtype=torch.float32, device=device)
-            comm.all_reduce(flag)              # number of ranks that failed
-            if float(flag.item()) > 0:
                 use_sp = False
                 sp_mod._SP = None
+            comm_used = comm
 
     H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
     i2v = args.workload.startswith("c4")
@@ -332,10 +355,11 @@ def main():
         vae.enable_tiling()
         z = torch.randn(1, 16, temp, H // 8, W // 8, generator=torch.Generator().manual_seed(5)).to(device)
         comm = sp_mod.get_sequence_parallel_comm() if use_sp else None
-        # un-tiled temporal context parallelism needs every full-resolution activation of a rank's frame range resident:
-        # ~8 live buffers of (8 x frames) x 770 x 1282 x 256 ch bf16 at the widest level
-        cp_bytes = 8 * (8 * -(-temp // max(world, 1))) * (H + 2) * (W + 2) * 256 * 2
-        use_cp = use_sp and -(-temp // world) >= 2 and temp // world >= 2 and cp_bytes < 0.7 * torch.cuda.get_device_properties(0).total_memory
+        # un-tiled temporal context parallelism: the live set of the one-pass decode is its widest layer (the first resnet of
+        # the full-resolution level: input 256 ch + normalised input 256 ch + conv1 output 128 ch of 8 x frames; vae.py hands
+        # every dead activation back) + 30 % for the allocator and the lower levels
+        cp_bytes = 1.3 * (8 * -(-temp // max(world, 1))) * (H + 2) * (W + 2) * (256 + 256 + 128) * 2
+        use_cp = use_sp and -(-temp // world) >= 2 and temp // world >= 2 and cp_bytes < 0.85 * torch.cuda.get_device_properties(0).total_memory
         dcfg, dsd, pipe, sp = None, None, None, None
 
         def one_video(seed):

@@ -136,6 +136,16 @@ class NativeComm:
                                           C.c_longlong(s_.numel() * s_.element_size()), self._cur()))
         self._Handle(self).wait()
 
+    def shift_start(self, send_t, recv_t):
+        """the halo pass queued on the communicator's stream; wait() of the returned handle orders the current stream
+        behind it (pf_comm_wait) -- kernels launched in between run while the frames travel"""
+        self._no_recording("shift")
+        s_ = send_t.contiguous()
+        assert recv_t.is_contiguous()
+        check(self._lib.pf_halo_send_recv(self._h, C.c_void_p(s_.data_ptr()), C.c_void_p(recv_t.data_ptr()),
+                                          C.c_longlong(s_.numel() * s_.element_size()), self._cur()))
+        return self._Handle(self)
+
     def all_gather_v(self, send, recv, counts):
         """recv <- concatenation of every rank's `send` (element counts per rank in `counts`)"""
         self._no_recording("all_gather_v")

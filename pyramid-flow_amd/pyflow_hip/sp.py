@@ -190,6 +190,27 @@ class SPComm:
         if staged and hr is not None:
             recv_t.copy_(hr)
 
+    def shift_start(self, send_t, recv_t):
+        """`shift` without waiting (RCCL only): returns a handle whose wait() makes the CURRENT stream wait for the received
+        halo -- the host does not block, kernels queued meanwhile overlap with the transfer.  None = completed inline."""
+        if not self.native:
+            self.shift(send_t, recv_t)
+            return None
+        ops = []
+        if self.rank + 1 < self.world:
+            ops.append(dist.P2POp(dist.isend, send_t.contiguous(), self._global(self.rank + 1), self.group))
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.irecv, recv_t, self._global(self.rank - 1), self.group))
+        if not ops:
+            return None
+        reqs = dist.batch_isend_irecv(ops)
+
+        class _H:
+            def wait(self_inner):
+                for r_ in reqs:
+                    r_.wait()
+        return _H()
+
     def warm_p2p(self, device):
         """Create the point-to-point channels the tile-parallel decode uses (neighbour strips r -> r+1, column blocks
         r -> 0) before anything is timed: RCCL sets a pair's channel up lazily at its first send / recv."""

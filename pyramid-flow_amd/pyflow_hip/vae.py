@@ -58,12 +58,25 @@ class PBuf:
         assert n >= 2, "context parallelism needs >= 2 frames per rank at every temporal level"
         self.halo.shift(self.t[n * fs:(n + 2) * fs], self.t[0:2 * fs])
 
+    def exchange_halo_start(self):
+        """the same exchange without waiting for it (the reference blocks on req_recv.wait() before the conv,
+        context_parallel_ops.py:110): returns a handle whose wait() orders the CURRENT stream behind the received frames,
+        or None when the transport completed inline (gloo tests, one rank).  Output frames >= 2 of the conv that follows
+        do not read the two cache slots and are launched before the wait."""
+        n, fs = self.cur, self.fs
+        assert n >= 2, "context parallelism needs >= 2 frames per rank at every temporal level"
+        start = getattr(self.halo, "shift_start", None)
+        if start is None:
+            self.halo.shift(self.t[n * fs:(n + 2) * fs], self.t[0:2 * fs])
+            return None
+        return start(self.t[n * fs:(n + 2) * fs], self.t[0:2 * fs])
+
     def shift_cache(self):
         """slots[0:2] <- last two of slots[0:2+cur]  (cache_front_feat update, causal_conv.py:132,143).  Inside a tile
         program the update is only RECORDED (`pending`): all buffers of a chunk are shifted by one pf_shift_caches launch
         at the end of the chunk -- nothing reads the cache slots again before the next chunk."""
-        if self.halo is not None:
-            return            # context-parallel mode: one pass per rank, the slots are filled by exchange_halo()
+        if self.halo is not None or getattr(self, "transient", False):
+            return            # context-parallel / one-pass mode: no chunk follows (the slots are filled by exchange_halo())
         n = self.cur
         if self.pending is not None:
             if n >= 1:
@@ -109,53 +122,74 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
     down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2.
     tdown = 2: CausalTemporalDownsample2x (:458-502).  First chunk / whole clip: windows start at the first cache slot
     (two zero frames in front).  later_chunk: only ONE frame of context (modeling_causal_conv.py:139-140), i.e. the
-    windows start at the second cache slot and an even chunk of Tc frames gives Tc / 2 outputs."""
+    windows start at the second cache slot and an even chunk of Tc frames gives Tc / 2 outputs.
+    Context-parallel mode (src.halo): the two cache slots come from the previous rank; output frames >= 2 do not read them
+    and are launched while that exchange is in flight, frames 0-1 after it (CausalConv3d.context_parallel_forward,
+    modeling_causal_conv.py:95-114, without its blocking wait)."""
     lib = L.load()
-    if cw.kt == 3 and src.halo is not None:
-        src.exchange_halo()
-    d = ConvDesc()
-    d.X = src.t.data_ptr()
-    d.W = cw.w.data_ptr()
-    d.bias = cw.b.data_ptr()
     slot_shift = 0
+    T_in = Tc
     if tdown > 1:          # causal temporal stride: frames [0, 0, x0 .. x(Tc-1)] -> floor((Tc - 1) / 2) + 1 outputs
         if later_chunk:
             assert Tc % tdown == 0, "later chunks of a strided temporal conv must hold an even number of frames"
             Tc, slot_shift = Tc // tdown, 1
         else:
             Tc = (Tc - 1) // tdown + 1
-    d.T, d.H, d.W_ = Tc, src.H // down, src.W // down
-    d.in_sh = d.in_sw = down
-    d.in_st = tdown
-    d.Hp, d.Wp, d.Cin = src.Hp, src.Wp, src.Cp
-    d.kt, d.kh, d.kw = cw.kt, cw.kh, cw.kw
-    assert cw.cin_p == src.Cp
     # first temporal slot the taps touch (kt = 3: the two cache slots + the frame; kt = 1: the frame itself) and, for
     # spatial taps, the padded origin (row -1, col -1) instead of the first interior pixel
     slot0 = 2 - (cw.kt - 1) + slot_shift
-    d.in_base_off = slot0 * src.fs + ((src.Wp + 1) * src.Cp if cw.kh == 1 else 0)
-    d.N, d.n_valid = cw.N, cw.n_valid
-    d.st, d.sh, d.sw, d.Cg = st, sh, sw, cw.Cg
-    if dst_raw is not None:
-        t, Ht, Wt, Cp, frame0 = dst_raw
-        d.Y = t.data_ptr()
-        d.Hop, d.Wop, d.Cout_pitch = Ht, Wt, Cp
-        d.out_base_off = frame0 * Ht * Wt * Cp
-        d.n_valid = Cp
-        d.Cg = Cp
+    assert cw.cin_p == src.Cp
+
+    def launch(f0, nf):
+        """output frames [f0, f0 + nf) of the launch (input frames f0 * tdown ...)"""
+        d = ConvDesc()
+        d.X = src.t.data_ptr()
+        d.W = cw.w.data_ptr()
+        d.bias = cw.b.data_ptr()
+        d.T, d.H, d.W_ = nf, src.H // down, src.W // down
+        d.in_sh = d.in_sw = down
+        d.in_st = tdown
+        d.Hp, d.Wp, d.Cin = src.Hp, src.Wp, src.Cp
+        d.kt, d.kh, d.kw = cw.kt, cw.kh, cw.kw
+        d.in_base_off = (slot0 + f0 * tdown) * src.fs + ((src.Wp + 1) * src.Cp if cw.kh == 1 else 0)
+        d.N, d.n_valid = cw.N, cw.n_valid
+        d.st, d.sh, d.sw, d.Cg = st, sh, sw, cw.Cg
+        # the first output frame of the WHOLE conv may be dropped (t_shift = -1: is_init_image); a sub-range that starts
+        # later carries the shift in its base offset instead (its own first frame must not be dropped)
+        ts_k, ts_off = (t_shift, 0) if f0 == 0 else (0, t_shift)
+        if dst_raw is not None:
+            t, Ht, Wt, Cp, frame0 = dst_raw
+            d.Y = t.data_ptr()
+            d.Hop, d.Wop, d.Cout_pitch = Ht, Wt, Cp
+            d.out_base_off = (frame0 + f0 * st + ts_off) * Ht * Wt * Cp
+            d.n_valid = Cp
+            d.Cg = Cp
+        else:
+            d.Y = dst.t.data_ptr()
+            d.Hop, d.Wop, d.Cout_pitch = dst.Hp, dst.Wp, dst.Cp
+            d.out_base_off = dst.off(2) + (f0 * st + ts_off) * dst.fs
+            assert dst.H == src.H * sh // down and dst.W == src.W * sw // down
+        d.flags = GEMM_GATE_RES if res is not None else 0
+        d.res = res.t.data_ptr() if res is not None else None
+        if res is not None:
+            assert (res.Hp, res.Wp, res.Cp) == (dst.Hp, dst.Wp, dst.Cp)
+        d.out_scale = 1.0
+        d.out_t_shift = ts_k
+        ops.PROFILER.launch("conv3d", 2.0 * nf * (src.H // down) * (src.W // down) * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
+                            lambda: check(lib.pf_conv3d_bf16(C.byref(d), stream())))
+
+    if cw.kt == 3 and src.halo is not None:
+        if tdown == 1 and Tc > 2:
+            h = src.exchange_halo_start()
+            launch(2, Tc - 2)                  # these frames read slots >= 2 only
+            if h is not None:
+                h.wait()
+            launch(0, 2)
+        else:
+            src.exchange_halo()
+            launch(0, Tc)
     else:
-        d.Y = dst.t.data_ptr()
-        d.Hop, d.Wop, d.Cout_pitch = dst.Hp, dst.Wp, dst.Cp
-        d.out_base_off = dst.off(2)
-        assert dst.H == src.H * sh // down and dst.W == src.W * sw // down
-    d.flags = GEMM_GATE_RES if res is not None else 0
-    d.res = res.t.data_ptr() if res is not None else None
-    if res is not None:
-        assert (res.Hp, res.Wp, res.Cp) == (dst.Hp, dst.Wp, dst.Cp)
-    d.out_scale = 1.0
-    d.out_t_shift = t_shift
-    ops.PROFILER.launch("conv3d", 2.0 * Tc * (src.H // down) * (src.W // down) * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
-                        lambda: check(lib.pf_conv3d_bf16(C.byref(d), stream())))
+        launch(0, Tc)
     if dst is not None:
         dst.cur = Tc * st + t_shift
 
@@ -195,16 +229,28 @@ class _TileProgram:
         z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.dev)  # noqa: E731
         self.a_x, self.a_q, self.a_k, self.a_o = z(tm, npad, ca), z(tm, npad, ca), z(tm, npad, ca), z(tm, npad, ca)
         self.a_vt = z(ca, npad)
-        self.a_s = z(npad, npad)
+        self.q_block = n if n <= 4096 else 2048
+        self.a_s = z(_ru(self.q_block, 128), npad)
 
     def buf(self, name, level_t, H, W, Cc):
         b = self.bufs.get(name)
         if b is None:
             b = PBuf(name, self.tmax[level_t], H, W, Cc, self.dev, self.pool)
             b.halo = getattr(self, "halo", None)
+            b.transient = getattr(self, "transient", False)
             b.pending = self.pending
             self.bufs[name] = b
         return b
+
+    def release(self, b):
+        """TRANSIENT mode (the one-pass un-tiled decode of a context-parallel rank: no chunk follows, so no cache slot has
+        to survive): a buffer's storage goes back to the allocator after its last reader has been queued -- the live set
+        is then a few layers (x, n1, h at the widest level) instead of all ~70 activations of the decoder, which is what
+        lets a rank hold 16 latent frames (128 frames of 768 x 1280) in HBM.  Everything runs on one stream, so the
+        caching allocator may hand the block to the next layer at once.  No-op for the chunked tile programs."""
+        if getattr(self, "transient", False) and b is not None and self.bufs.get(b.name) is b:
+            del self.bufs[b.name]
+            b.t = None
 
     def reset(self):
         if self.pool is not None and self.pool.get("__owner__") is not self:
@@ -274,15 +320,20 @@ class _TileProgram:
         h = self.buf(p + "h", lvl, x.H, x.W, cout)
         conv(n1, h, self.cw[p + "conv1"], Tc)
         n1.shift_cache()
-        n2 = self.buf(p + "n2", lvl, x.H, x.W, cout)
-        self.gn(h, n2, p + "norm2")
+        self.release(n1)
         res = x
         if (p + "conv_shortcut") in self.cw:
             res = self.buf(p + "sc", lvl, x.H, x.W, cout)
             conv(x, res, self.cw[p + "conv_shortcut"], Tc)
+            self.release(x)                     # the wide input is dead once the shortcut has been taken from it
+        n2 = self.buf(p + "n2", lvl, x.H, x.W, cout)
+        self.gn(h, n2, p + "norm2")
+        self.release(h)
         out = self.buf(out_name, lvl, x.H, x.W, cout)
         conv(n2, out, self.cw[p + "conv2"], Tc, res=res)
         n2.shift_cache()
+        self.release(n2)
+        self.release(res)                       # = x without a shortcut conv: the block's input is not read again
         return out
 
     def mid_attention(self, x, out_name, side="decoder", lvl=0):
@@ -298,14 +349,19 @@ class _TileProgram:
         ops.gemm(self.a_x, wq, self.a_q, npad, ca, ca, ca, ca, ca, bias=bq, batch=Tc, strideA=npad * ca, strideC=npad * ca)
         ops.gemm(self.a_x, wk, self.a_k, npad, ca, ca, ca, ca, ca, bias=bk, batch=Tc, strideA=npad * ca, strideC=npad * ca)
         out = self.buf(out_name, lvl, x.H, x.W, x.C)
+        qb = self.q_block                       # query rows per score block (= n for tile-sized frames)
         for f in range(Tc):
             fo = f * npad * ca
             # V^T = Wv . X^T  (bias folded into the PV epilogue: rows of P sum to 1)
             ops.gemm(wv, self.a_x, self.a_vt, ca, npad, ca, ca, ca, npad, c_off=0, a_off=0, w_off=fo)
-            ops.gemm(self.a_q, self.a_k, self.a_s, n, npad, ca, ca, ca, npad, a_off=fo, w_off=fo)
-            check(L.load().pf_softmax_rows(C.c_void_p(self.a_s.data_ptr()), C.c_int(npad), C.c_int(n), C.c_int(npad),
-                                           C.c_int(n), C.c_float(v.attn_scale), stream()))
-            ops.gemm(self.a_s, self.a_vt, self.a_o, n, ca, npad, npad, npad, ca, bias=bv, c_off=fo)
+            # scores of a BLOCK of query rows at a time: S[qb, npad] instead of [n, npad] (an un-tiled 768p frame has
+            # 15 360 tokens: 472 MB of scores per frame if materialised whole; 63 MB with 2 048-row blocks)
+            for q0 in range(0, n, qb):
+                nq = min(qb, n - q0)
+                ops.gemm(self.a_q, self.a_k, self.a_s, nq, npad, ca, ca, ca, npad, a_off=fo + q0 * ca, w_off=fo)
+                check(L.load().pf_softmax_rows(C.c_void_p(self.a_s.data_ptr()), C.c_int(npad), C.c_int(n), C.c_int(npad),
+                                               C.c_int(nq), C.c_float(v.attn_scale), stream()))
+                ops.gemm(self.a_s, self.a_vt, self.a_o, nq, ca, npad, npad, npad, ca, bias=bv, c_off=fo + q0 * ca)
         # to_out + residual, written into the padded image (1x1x1 conv form, A un-padded)
         lib = L.load()
         for f in range(Tc):
@@ -346,13 +402,16 @@ class _TileProgram:
         zb.cur = nt
         pq = self.buf("pq", 0, th, tw, lat)
         conv(zb, pq, v.convs["post_quant_conv"], nt)
+        self.release(zb)
         top = cfg["block_out_channels"][-1]
         x = self.buf("conv_in", 0, th, tw, top)
         conv(pq, x, v.convs["decoder.conv_in"], nt)
         pq.shift_cache()
+        self.release(pq)
         x = self.resnet(x, "decoder.mid_block.resnets.0.", 0, "mid.r0", top)
-        x = self.mid_attention(x, "mid.attn")
-        x = self.resnet(x, "decoder.mid_block.resnets.1.", 0, "mid.r1", top)
+        xa = self.mid_attention(x, "mid.attn")
+        self.release(x)
+        x = self.resnet(xa, "decoder.mid_block.resnets.1.", 0, "mid.r1", top)
         rev = list(reversed(cfg["block_out_channels"]))
         lvl = 0
         for i, co in enumerate(rev):
@@ -363,18 +422,22 @@ class _TileProgram:
                 y = self.buf(f"up{i}.sp", lvl, x.H * 2, x.W * 2, co)
                 conv(x, y, v.convs[p + "upsamplers.0.conv"], x.cur, sh=2, sw=2)
                 x.shift_cache()
+                self.release(x)
                 x = y
             if cfg["temporal_up_sample"][i]:
                 y = self.buf(f"up{i}.tp", lvl + 1, x.H, x.W, co)
                 conv(x, y, v.convs[p + "temporal_upsamplers.0.conv"], x.cur, st=2, t_shift=-1 if first else 0)
                 x.shift_cache()
+                self.release(x)
                 x = y
                 lvl += 1
         n = self.buf("norm_out", lvl, x.H, x.W, x.C)
         self.gn(x, n, "decoder.conv_norm_out")
+        self.release(x)
         conv(n, None, v.convs["decoder.conv_out"], n.cur, dst_raw=(out_tile, x.H, x.W, 8, out_frame0))
         nf = n.cur
         n.shift_cache()
+        self.release(n)
         self.end_chunk()
         return nf
 
@@ -785,6 +848,7 @@ class CausalVideoVAE(DeviceModuleAPI):
         if prog is None:
             prog = _TileProgram(self, H, W, nt, nt)
             prog.halo = comm if P > 1 else None
+            prog.transient = True              # one pass per rank: activations are handed back as soon as they are dead
             self._programs[key] = prog
         prog.reset()
         n_t = sum(self.cfg["temporal_up_sample"])

@@ -98,7 +98,7 @@ def _launch(world, script, args, tmp_path):
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=300)
+            o, _ = p.communicate(timeout=900)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -126,6 +126,14 @@ def test_sp_generate_and_tile_parallel_decode(tmp_path, world):
 def test_vae_context_parallel(tmp_path, world, T):
     """temporal context-parallel VAE decode (halo exchange per causal conv, uneven frame ranges) == single process"""
     _launch(world, "cp_worker.py", [T], tmp_path)
+
+
+def test_vae_context_parallel_768p_two_ranks(tmp_path):
+    """the context-parallel decode at the headline latent size (96 x 160, released channel widths): 4 latent frames over 2
+    ranks -> 25 frames of 768 x 1280, un-tiled (15 360-token mid-block attention in 2 048-row score blocks, transient
+    activation buffers, halo exchange per causal conv with the halo-independent frames launched first); every frame
+    against the single-rank un-tiled decode, which tests/test_fulldepth_oracle_gpu.py pins to the fp32 oracle."""
+    _launch(2, "cp_worker.py", [4, "768p"], tmp_path)
 
 
 def test_rccl_api_on_one_rank():
