@@ -37,7 +37,8 @@ WORKLOADS = {
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E (same guide)
-PMC_PROFILE = "r02_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the `traffic` fields are replayed from
+PMC_PROFILE = "r03_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the DiT kernels' `traffic` fields are replayed from
+PMC_PROFILE_VAE = "r03_pmc_vae_tile.json"      # ... and the VAE kernels' (one tile-chunk window at the timed launch shapes)
 
 
 def build_pipeline(device, tiny=False, mmdit=False, stages=None):
@@ -479,14 +480,36 @@ def main():
     try:
         with open(pmc_path, "rb") as f:
             raw = f.read()
-        pm = json.loads(raw)["kernels"]
         import hashlib           # git blob id of the file the numbers are replayed from: a stale replay is visible
+        pm = json.loads(raw)["kernels"]
         pmc_blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]
     except Exception:
         pm, pmc_blob = {}, None
 
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_PROFILE_VAE), "rb") as f:
+            raw_v = f.read()
+        pmv = json.loads(raw_v)["kernels"]
+        pmc_blob_vae = hashlib.sha1(b"blob %d\0" % len(raw_v) + raw_v).hexdigest()[:12]
+    except Exception:
+        pmv, pmc_blob_vae = {}, None
+
+    def vae_traffic(kind):
+        """HBM-side bytes per launch of the decode's kernels at the sampled tile's launch shapes (the PMC passes ran the same
+        tile): GroupNorm passes directly; `conv3d` = launch-weighted mean over the convolution kernels"""
+        if kind in ("gn_stats", "gn_apply"):
+            for n, v in pmv.items():
+                if kind in n:
+                    return round(v["hbm_bytes_per_launch"])
+            return None
+        conv = [v for n, v in pmv.items() if ("true" in n and "gemm" in n) or "conv_narrow" in n]
+        nl = sum(v["launches"] for v in conv)
+        return round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in conv) / nl) if nl else None
+
     def pmc_traffic(name):
-        key = {"attention": "attn_kernel", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
+        if name in ("conv3d", "gn_stats", "gn_apply"):
+            return vae_traffic(name)
+        key = {"attention": "attn64_kernel<2, 1>", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
         key = key.replace("gemm256_kernel<128>", "gemm256_kernel<128, false").replace("gemm256_kernel<192>", "gemm256_kernel<192, false") \
                  .replace("gemm256_kernel<256>", "gemm256_kernel<256, false")
         for n, v in pm.items():
@@ -496,6 +519,10 @@ def main():
     for r in [roof] + list(extra.values()):
         if r is not None and r.get("traffic") is None:
             r["traffic"] = pmc_traffic(r["kernel"])
+    for k_, r_ in extra.items():
+        if k_.startswith("vae:") and r_.get("traffic") is not None:
+            r_["traffic_note"] = (f"(2*FETCH_SIZE + WRITE_SIZE) per launch from rocprofv3 --pmc passes over the same tile-chunk "
+                                  f"window (profiles/{PMC_PROFILE_VAE}, git blob {pmc_blob_vae}); REPLAYED, not measured in this run")
     if roof is not None and roof["traffic"] is not None:
         roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
                                 f"the launches of one full-width forward at L=15488; REPLAYED from profiles/{PMC_PROFILE} "
