@@ -448,12 +448,21 @@ int main(int argc, char** argv) {
     ABLV("abl: no softmax, no MFMA (LDS+DMA+barrier only)", lab::A_NOSM | lab::A_NOMFMA, 3, false);
     ABLV("abl: MFMA only (no softmax, sync, LDS)", lab::A_NOSM | lab::A_NOSYNC | lab::A_NOLDS, 3, false);
     const int grid64 = ((pl.nqt + 1) / 2) * H * B;
-    vars.push_back({"attn64_kernel<2> (64 rows / wave, 256 / WG)", [&] { hipLaunchKernelGGL((attn64_kernel<2>), dim3(grid64), dim3(256), 0, st, a); }, true});
+    constexpr int SM64 = 2 * ABUF + 4 * 64 * HD * 2, SM128 = 2 * ABUF + 8 * 64 * HD * 2;
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
+    CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
+    const int grid128 = ((pl.nqt + 3) / 4) * H * B;
+    vars.push_back({"attn64_kernel<2> (64 rows / wave, 256 / WG)", [&] { hipLaunchKernelGGL((attn64_kernel<2>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     a.dbg = d_dbg;
     a.wgflags = d_flags;
     vars.push_back({"attn64 FAST (m = 0, no row max) + FIXUP launch", [&] {
-        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), 0, st, a);
-        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), 0, st, a); }, true});
+        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), SM64, st, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     static pf_attn_desc desc2;
     desc2 = desc;
     desc2.O = dout;
@@ -461,9 +470,12 @@ int main(int argc, char** argv) {
     desc2.workspace_bytes = (long long)nwg_max * 4 * 4;
     printf("pf_attention_which(desc + scratch) = %d\n", pf_attention_which(&desc2));
     vars.push_back({"pf_attention_bf16 with scratch (library dispatch)", [&] { pf_attention_bf16(&desc2, st); }, true});
-    vars.push_back({"attn64 FAST alone", [&] { hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), 0, st, a); }, true});
-    vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), 0, st, a); }, true});
-    vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), 0, st, a); }, false});
+    vars.push_back({"attn64 8 waves / 512 rows: FAST + FIXUP", [&] {
+        hipLaunchKernelGGL((attn64_kernel<2, 1, 8>), dim3(grid128), dim3(512), SM128, st, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4, 8>), dim3(grid128), dim3(512), SM128, st, a); }, true});
+    vars.push_back({"attn64 FAST alone", [&] { hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), SM64, st, a); }, true});
+    vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), SM64, st, a); }, true});
+    vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), SM64, st, a); }, false});
     ABLV("stamped (occ 3)", lab::A_STAMP, 3, true);
 
     // reference output of the shipped kernel
@@ -552,8 +564,8 @@ int main(int argc, char** argv) {
     }
     for (int v64 = 2; v64 <= 3; ++v64) {
         CK(hipMemset(d_dbg, 0, nwg_max * 4 * lab::NPH * 4));
-        if (v64 == 2) hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), 0, st, a);
+        if (v64 == 2) hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), SM64, st, a);
+        else hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), SM64, st, a);
         CK(hipStreamSynchronize(st));
         std::vector<unsigned> hd((size_t)grid64 * 4 * 8);
         CK(hipMemcpy(hd.data(), d_dbg, hd.size() * 4, hipMemcpyDeviceToHost));

@@ -377,10 +377,13 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     // Large pre-scaled problems with caller scratch: the 64-rows-per-wave kernel as a fast pass + a fix-up pass
     // (attention_w64.h; +8...13 % over the kernel below from L = 3 008 up: profiles/r03_attention_w64_fast_fixup.log).
     if (use_w64(d)) {
+        constexpr int SM64 = 2 * ABUF + 4 * 64 * HD * 2;
         const int grid64 = ((a.nqt + 1) / 2 - a.qt0 / 2) * a.H * a.B;
         a.wgflags = (int*)d->workspace;
-        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), 0, stream, a);
+        PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 1>), SM64);
+        PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
+        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), SM64, stream, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
         hipError_t e64 = hipGetLastError();
         if (e64 != hipSuccess) return pf_set_err(hipGetErrorString(e64));
         return 0;

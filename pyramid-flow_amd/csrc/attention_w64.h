@@ -29,20 +29,27 @@
 // The fast form removes ~47 of ~127 vector instructions per 32 rows x 64 keys: profiles/r03_mfma_valu_overlap_microbench.log
 // shows v_exp_f32 costing 8.4 cycles and every other vector op ~4.5 next to MFMAs, i.e. this kernel is bound by vector
 // issue, not by the matrix pipe.
-template <int OCC, int MODE = 0>
-__global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
+// NW = waves per workgroup (4: 256 query rows, two workgroups per CU; 8: 512 rows, one workgroup per CU -- every K / V^T tile
+// then serves twice the rows: half the LDS-DMA pieces per wave and tile, whose issue costs a wave 100-150 cycles each).
+template <int OCC, int MODE = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     constexpr int ABL = MODE;
     constexpr bool FAST = (MODE & 1) != 0, FIXUP = (MODE & 4) != 0;
+    constexpr int PJ = 8 / NW;                 // DMA pieces per wave of each of the K and V^T tiles (8 pieces of 8 rows each)
+    constexpr int NT = NW / 2;                 // 128-row query tiles (the granularity of tile_kv_end / q_row_begin) per workgroup
     if (FIXUP) {
-        const int* f = p.wgflags + 4 * blockIdx.x;
-        if ((f[0] | f[1] | f[2] | f[3]) == 0) return;
+        const int* f = p.wgflags + NW * blockIdx.x;
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) any |= f[i];
+        if (any == 0) return;
     }
-    constexpr int QB2 = 256, QWAVE = 64 * HD * 2;                 // 8 KiB of Q per wave
-    __shared__ __attribute__((aligned(16))) char smem[2 * ABUF + 4 * QWAVE];
+    constexpr int QB2 = 64 * NW, QWAVE = 64 * HD * 2;             // 8 KiB of Q per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * ABUF (K | V^T tile ring) + NW * QWAVE (Q rows)
     char* const sq = smem + 2 * ABUF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nq2 = (p.nqt + 1) >> 1, qt0 = p.qt0 >> 1;
+    const int nq2 = (p.nqt + NT - 1) / NT, qt0 = p.qt0 / NT;
     const int nq_run = nq2 - qt0;
     const int nwg = nq_run * p.H * p.B;
     const int t = xcd_remap(blockIdx.x, nwg);
@@ -76,8 +83,10 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
         wmax = max(wmax, __shfl_xor(wmax, o_));
         wmin = min(wmin, __shfl_xor(wmin, o_));
     }
-    int kv_end = p.tile_kv_end[b * p.nqt + 2 * qt];
-    if (2 * qt + 1 < p.nqt) kv_end = max(kv_end, p.tile_kv_end[b * p.nqt + 2 * qt + 1]);
+    int kv_end = 0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        if (NT * qt + i < p.nqt) kv_end = max(kv_end, p.tile_kv_end[b * p.nqt + NT * qt + i]);
     const int ntiles = (kv_end + KB - 1) / KB;
     const int wmax_s = __builtin_amdgcn_readfirstlane(wmax), wmin_s = __builtin_amdgcn_readfirstlane(wmin);
     // tiles this wave computes: the text tiles and every image tile below the largest visibility bound of its 64 rows
@@ -89,11 +98,11 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
     const char* const kbase = (const char*)(p.K + (long long)b * p.sK + h * p.hs_qk);
     const char* const vbase = (const char*)(p.Vt + (long long)b * p.sVb + (long long)h * p.sVh);
     const int ldk2 = p.ldk * 2;
-    int prow[2];
-    unsigned pc2[2], voff[2];
+    int prow[PJ];
+    unsigned pc2[PJ], voff[PJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int i = wid * 2 + j;
+    for (int j = 0; j < PJ; ++j) {
+        const int i = wid * PJ + j;
         prow[j] = 8 * i + (lane >> 3);
         pc2[j] = (unsigned)(((lane & 7) ^ (((i & 1) << 2) + (lane >> 4))) * 16);
         voff[j] = (unsigned)(prow[j] * p.Lp * 2) + pc2[j];
@@ -101,10 +110,10 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
     auto issue_k = [&](int jt, int buf, int j) {
         const int last = p.L - 1 - jt * KB;                 // rows of the tile beyond the sequence re-read its last key
         const unsigned off = (unsigned)(min(prow[j], last) * ldk2) + pc2[j];
-        glds16(kbase + (long long)jt * KB * ldk2 + off, smem + buf * ABUF + wid * 2048 + j * 1024);
+        glds16(kbase + (long long)jt * KB * ldk2 + off, smem + buf * ABUF + (wid * PJ + j) * 1024);
     };
     auto issue_v = [&](int jt, int buf, int j) {
-        glds16(vbase + (long long)jt * (KB * 2) + voff[j], smem + buf * ABUF + KTILE + wid * 2048 + j * 1024);
+        glds16(vbase + (long long)jt * (KB * 2) + voff[j], smem + buf * ABUF + KTILE + (wid * PJ + j) * 1024);
     };
     // the wave's own 64 query rows -> LDS, same 128-byte-row image and chunk swizzle as a K tile (piece k = rows 8k..8k+7:
     // lane -> row 8k + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ ((row >> 1) & 7)); only this wave reads them
@@ -235,12 +244,13 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
     // ---- prologue: Q rows and tiles 0, 1 in flight; tile 0 and Q landed; first K / Q fragments requested
     if (ntiles > 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { issue_k(0, 0, j); issue_v(0, 0, j); }
+        for (int j = 0; j < PJ; ++j) { issue_k(0, 0, j); issue_v(0, 0, j); }
     }
     if (ntiles > 1) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { issue_k(1, 1, j); issue_v(1, 1, j); }
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        for (int j = 0; j < PJ; ++j) { issue_k(1, 1, j); issue_v(1, 1, j); }
+        if (PJ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -388,8 +398,13 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
                 PF_SEG();
                 if (g < 2) exp_slot(g + 2, sb, psb, pb);
                 if (more) {
-                    if (g < 2) issue_k(jt + 2, buf, g);
-                    else issue_v(jt + 2, buf, g - 2);
+                    if (PJ == 2) {
+                        if (g < 2) issue_k(jt + 2, buf, g);
+                        else issue_v(jt + 2, buf, g - 2);
+                    } else {
+                        if (g == 0) issue_k(jt + 2, buf, 0);
+                        if (g == 1) issue_v(jt + 2, buf, 0);
+                    }
                 }
                 PF_SEG();
             }
@@ -407,8 +422,13 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
                 PF_SEG();                      // the MFMA pair first: the exponentials of the next slot run while it executes
                 if (g < 3) exp_slot(g + 1, sb, psb, pb);
                 if (more) {
-                    if (g < 2) issue_k(jt + 2, buf, g);
-                    else issue_v(jt + 2, buf, g - 2);
+                    if (PJ == 2) {
+                        if (g < 2) issue_k(jt + 2, buf, g);
+                        else issue_v(jt + 2, buf, g - 2);
+                    } else {
+                        if (g == 0) issue_k(jt + 2, buf, 0);
+                        if (g == 1) issue_v(jt + 2, buf, 0);
+                    }
                 }
                 PF_SEG();
             }
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
             if (ABL & 2) ph[7] += 1;
         } else if (more) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { issue_k(jt + 2, buf, j); issue_v(jt + 2, buf, j); }
+            for (int j = 0; j < PJ; ++j) { issue_k(jt + 2, buf, j); issue_v(jt + 2, buf, j); }
         }
     };
 
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((ABL & 2) && lane == 0 && p.dbg) {
-        unsigned* d_ = p.dbg + ((size_t)blockIdx.x * 4 + wid) * 8;
+        unsigned* d_ = p.dbg + ((size_t)blockIdx.x * NW + wid) * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) d_[i] = ph[i];
     }
@@ -446,7 +466,7 @@ __global__ __launch_bounds__(256, OCC) void attn64_kernel(const AArgs p) {
             bad = bad || (valid && !(lx > 1e-30f && lx < 1e30f));
         }
         const int any_bad = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
-        if (lane == 0) p.wgflags[4 * blockIdx.x + wid] = any_bad;
+        if (lane == 0) p.wgflags[NW * blockIdx.x + wid] = any_bad;
     }
 
     // ---- epilogue: O = o / l, bf16, 16-byte stores (a lane pair (l, l^32) holds 8 consecutive features of a row after
