@@ -242,6 +242,44 @@ def generate_bf16_fixture():
                os.path.join(OUT, "generate_tiny_latents_bf16.pt"))
 
 
+class _BatchTextEncoder:
+    """the harness's stub prompt encoder over a LIST of prompts: one row per prompt (what the reference's encoders return)"""
+
+    def __init__(self):
+        self.inner = rh.StubTextEncoder()
+
+    def to(self, *_a, **_k):
+        return self
+
+    def __call__(self, prompt, device):
+        rows = [self.inner(p_, device) for p_ in ([prompt] if isinstance(prompt, str) else prompt)]
+        return tuple(torch.cat([r[i] for r in rows]) for i in range(3))
+
+
+def generate_batch_fixture():
+    """A batch of two prompts through the UNMODIFIED reference's generate() (pyramid_dit_for_video_gen_pipeline.py:1049-1053:
+    batch_size = len(prompt); one negative prompt per prompt, which is what its [negative | positive] concatenation
+    needs): the latents and every block-noise draw have batch shape, so the two samples share one random stream."""
+    dit = build_dit()
+    vae = build_vae()
+    pipe = rh.build_ref_pipeline(dit, vae, text_encoder=_BatchTextEncoder())
+    rh.patch_block_noise(pipe, rh.NoiseStream(1))
+    H, W, temp = 64, 128, 2
+    prompts = ["a cat", "a red fox in the snow"]
+    with torch.no_grad():
+        lat = pipe.generate(prompt=prompts, negative_prompt=[NEG, NEG], height=H, width=W, temp=temp,
+                            num_inference_steps=[2, 2, 2], video_num_inference_steps=[2, 2, 2], guidance_scale=7.0,
+                            video_guidance_scale=5.0, generator=torch.Generator().manual_seed(0), output_type="latent")
+    assert lat.shape[0] == 2
+    te = pipe.text_encoder
+    pe, pm, pp = te([p_ + ", hyper quality, Ultra HD, 8K" for p_ in prompts], None)
+    ne, nm, npool = te(NEG, None)
+    torch.save(dict(dit_cfg=synth.TINY_FLUX, dit_weight_seed=DIT_SEED, pos=(pe, pm, pp), neg=(ne, nm, npool),
+                    height=H, width=W, temp=temp, steps=[2, 2, 2], video_steps=[2, 2, 2], guidance=7.0,
+                    video_guidance=5.0, latent_seed=0, noise_seed=1, latents=lat),
+               os.path.join(OUT, "generate_tiny_latents_batch2.pt"))
+
+
 def scheduler_fixture():
     ref = rh.shims.load_reference()
     out = {}
@@ -265,6 +303,7 @@ if __name__ == "__main__":
     vae_fixture()
     generate_fixture()
     generate_bf16_fixture()
+    generate_batch_fixture()
     scheduler_fixture()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -212,41 +212,57 @@ class PyramidDiTForVideoGeneration:
     @torch.no_grad()
     def generate_one_unit(self, x, past, prompt_mask, pooled, num_inference_steps, is_first_frame):
         """:706-788.  x: fp32 device latent [C,1,h0,w0] at stage-0 resolution.  Returns list of per-stage latents."""
-        outs = []
-        C = x.shape[0]
+        return self._one_unit_batch([x], [past], [(None, prompt_mask, pooled)], num_inference_steps, is_first_frame)[0]
+
+    def _one_unit_batch(self, xs, pasts, ctxs, num_inference_steps, is_first_frame):
+        """generate_one_unit for a batch of samples (:706-788 with latents.shape[0] > 1).  The samples share nothing but
+        the random stream: per stage ONE block-noise draw of batch shape (as the reference's, :735), then each sample
+        runs its own step loop (its own prompt context and launch plan).  ctxs[b] = (embeds | None, mask, pooled);
+        embeds None = the context already encoded by the caller.  Returns outs[b][stage]."""
+        nb = len(xs)
+        outs = [[] for _ in range(nb)]
+        C = xs[0].shape[0]
         B = 2 if self.do_classifier_free_guidance else 1
+        xs = list(xs)
         for i_s in range(len(self.stages)):
-            self.scheduler.set_timesteps(num_inference_steps[i_s], i_s, device=None)
             if i_s > 0:
-                h, w = x.shape[-2] * 2, x.shape[-1] * 2
+                h, w = xs[0].shape[-2] * 2, xs[0].shape[-1] * 2
+                self.scheduler.set_timesteps(num_inference_steps[i_s], i_s, device=None)
                 ori_sigma = 1 - self.scheduler.ori_start_sigmas[i_s]
                 gamma = self.scheduler.config.gamma
                 alpha = 1 / (math.sqrt(1 + (1 / gamma)) * (1 - ori_sigma) + ori_sigma)
                 beta = alpha * (1 - ori_sigma) / math.sqrt(gamma)
-                noise = self.sample_block_noise(1, C, 1, h, w).to(self._device, torch.float32).contiguous()
+                noise = self.sample_block_noise(nb, C, 1, h, w).to(self._device, torch.float32).contiguous()
                 if self.sp is not None:          # rank-local RNG streams may differ: rank 0's draw is the one used
                     self.sp.broadcast(noise, 0)
-                xn = torch.empty(C, 1, h, w, dtype=torch.float32, device=self._device)
-                ops.renoise_upsample(x, noise, xn, C, h, w, alpha, beta, self._round)
-                x = xn
-            clips = past[i_s] + [x[None]]
-            shapes = [tuple(c.shape[2:]) for c in clips]
-            plan = self._plan(shapes, prompt_mask)
-            gs = self._guidance_scale if is_first_frame else self._video_guidance_scale
-            h, w = x.shape[-2], x.shape[-1]
-            for t in self.scheduler._timesteps_host:
-                tv = float(t)
-                if self._round:
-                    tv = float(torch.tensor(tv, dtype=torch.float64).to(torch.bfloat16))      # pipeline.py:750
-                vtok = self.dit.forward_tokens(plan, clips, [tv] * B, pooled, shared_clips=True)
-                ds = self.scheduler.dsigma()
-                if self._round:
-                    # scheduling_flow_matching.py:283: `(sigma_next - sigma) * model_output` multiplies a 0-dim
-                    # float64 TENSOR with a bf16 tensor -- the 0-dim operand is converted to the common dtype (bf16)
-                    # before the product, so the reference's bf16 path steps with bf16(dsigma)
-                    ds = float(torch.tensor(ds, dtype=torch.float64).to(torch.bfloat16))
-                ops.cfg_euler_step(vtok, vtok.stride(0), vtok.stride(1), x, C, h, w, gs, B == 2, ds, self._round)
-            outs.append(x)
+                for b in range(nb):
+                    xn = torch.empty(C, 1, h, w, dtype=torch.float32, device=self._device)
+                    ops.renoise_upsample(xs[b], noise[b:b + 1], xn, C, h, w, alpha, beta, self._round)
+                    xs[b] = xn
+            for b in range(nb):
+                x = xs[b]
+                emb, prompt_mask, pooled = ctxs[b]
+                if emb is not None:
+                    self.dit.encode_context(emb)
+                self.scheduler.set_timesteps(num_inference_steps[i_s], i_s, device=None)
+                clips = pasts[b][i_s] + [x[None]]
+                shapes = [tuple(c.shape[2:]) for c in clips]
+                plan = self._plan(shapes, prompt_mask)
+                gs = self._guidance_scale if is_first_frame else self._video_guidance_scale
+                h, w = x.shape[-2], x.shape[-1]
+                for t in self.scheduler._timesteps_host:
+                    tv = float(t)
+                    if self._round:
+                        tv = float(torch.tensor(tv, dtype=torch.float64).to(torch.bfloat16))      # pipeline.py:750
+                    vtok = self.dit.forward_tokens(plan, clips, [tv] * B, pooled, shared_clips=True)
+                    ds = self.scheduler.dsigma()
+                    if self._round:
+                        # scheduling_flow_matching.py:283: `(sigma_next - sigma) * model_output` multiplies a 0-dim
+                        # float64 TENSOR with a bf16 tensor -- the 0-dim operand is converted to the common dtype (bf16)
+                        # before the product, so the reference's bf16 path steps with bf16(dsigma)
+                        ds = float(torch.tensor(ds, dtype=torch.float64).to(torch.bfloat16))
+                    ops.cfg_euler_step(vtok, vtok.stride(0), vtok.stride(1), x, C, h, w, gs, B == 2, ds, self._round)
+                outs[b].append(x)
         return outs
 
     @torch.no_grad()
@@ -255,8 +271,11 @@ class PyramidDiTForVideoGeneration:
                  use_linear_guidance=False, alpha=0.5, negative_prompt=DEFAULT_NEGATIVE, num_images_per_prompt=1,
                  generator=None, output_type="pil", save_memory=True, cpu_offloading=False, inference_multigpu=False,
                  callback=None, prompt_embeds=None):
-        """:1006-1219.  `prompt_embeds=(embeds[1,Lt,C], mask[1,Lt], pooled[1,Cp], neg_embeds, neg_mask, neg_pooled)`
-        bypasses the text encoders (synthetic-prompt benchmark)."""
+        """:1006-1219.  `prompt_embeds=(embeds[B,Lt,C], mask[B,Lt], pooled[B,Cp], neg_embeds, neg_mask, neg_pooled)`
+        bypasses the text encoders (synthetic-prompt benchmark).  A list of B prompts (x `num_images_per_prompt`) is a
+        batch of B*n independent samples drawn from ONE latent / block-noise stream of batch shape (:1049-1053, :1100);
+        the negative prompt (one string, or one per prompt) is repeated to the batch -- the reference needs the caller to
+        pass B negative prompts, its [negative | positive] concatenation (:1082-1085) does not broadcast."""
         assert (temp - 1) % self.frame_per_unit == 0, "The frames should be divided by frame_per unit"
         assert height % 64 == 0 and width % 64 == 0, "height/width must be multiples of 64 (8 VAE x 4 pyramid x 2 patch)"
         n_st = len(self.stages)
@@ -270,50 +289,62 @@ class PyramidDiTForVideoGeneration:
             if isinstance(prompt, str):
                 prompt = prompt + ", hyper quality, Ultra HD, 8K"
             else:
-                assert isinstance(prompt, list) and len(prompt) == 1, "batch size 1"
+                assert isinstance(prompt, list) and len(prompt) >= 1
                 prompt = [p + ", hyper quality, Ultra HD, 8K" for p in prompt]
             pe, pm, pp = self.text_encoder(prompt, self._device)
             ne, nm, npool = self.text_encoder(negative_prompt or "", self._device)
         else:
             pe, pm, pp, ne, nm, npool = prompt_embeds
+        nb = pe.shape[0]
+        assert ne.shape[0] in (1, nb), "negative_prompt: one string, or one per prompt"
+        n_img = int(num_images_per_prompt)
         self._guidance_scale = guidance_scale
         self._video_guidance_scale = video_guidance_scale
         if use_linear_guidance:
             guidance_scale_list = [max(guidance_scale - alpha * t_, min_guidance_scale) for t_ in range(temp)]
-        if self.do_classifier_free_guidance:
-            pe = torch.cat([ne, pe], dim=0)
-            pp = torch.cat([npool, pp], dim=0)
-            pm = torch.cat([nm, pm], dim=0)
         self._round = (self.model_dtype == "bf16") and pe.dtype == torch.bfloat16
-        self.dit.encode_context(pe)
+        ctxs = []                # per sample: ([negative | positive] embeds, mask, pooled) -- :1082-1085 for its row pair
+        for b in range(nb):
+            nbi = b if ne.shape[0] == nb else 0
+            if self.do_classifier_free_guidance:
+                ctx = (torch.cat([ne[nbi:nbi + 1], pe[b:b + 1]], dim=0), torch.cat([nm[nbi:nbi + 1], pm[b:b + 1]], dim=0),
+                       torch.cat([npool[nbi:nbi + 1], pp[b:b + 1]], dim=0))
+            else:
+                ctx = (pe[b:b + 1], pm[b:b + 1], pp[b:b + 1])
+            ctxs += [ctx] * n_img                # repeat_interleave order of the text encoders' num_images_per_prompt
+        nb *= n_img
+        if nb == 1:                              # one sample: its context is encoded once for the whole run
+            self.dit.encode_context(ctxs[0][0])
+            ctxs = [(None, ctxs[0][1], ctxs[0][2])]
         C = self.dit.w.out_cols // 4
-        latents = self.prepare_latents(1, C, temp, height, width, pe.dtype, self._device, generator)
-        x = latents[0].to(self._device, torch.float32).contiguous()                 # [C,T,H,W]
+        latents = self.prepare_latents(nb, C, temp, height, width, pe.dtype, self._device, generator)
+        x = latents.to(self._device, torch.float32).contiguous()                    # [B,C,T,H,W]
         if self.sp is not None:              # pipeline.py:1089-1095 / 752-756: one broadcast instead of one per step
             self.sp.broadcast(x, 0)
         for _ in range(n_st - 1):                                                     # :1112-1116
-            Cc, T, H, W = x.shape
-            y = torch.empty(Cc, T, H // 2, W // 2, dtype=torch.float32, device=self._device)
-            ops.avgpool2(x, y, Cc * T, H, W, 2.0, self._round)
+            Bc, Cc, T, H, W = x.shape
+            y = torch.empty(Bc, Cc, T, H // 2, W // 2, dtype=torch.float32, device=self._device)
+            ops.avgpool2(x, y, Bc * Cc * T, H, W, 2.0, self._round)
             x = y
         num_units = 1 + (temp - 1) // self.frame_per_unit
-        generated = []
+        generated = [[] for _ in range(nb)]
         for unit_index in range(num_units):
             if callback:
                 callback(unit_index, num_units)
             if use_linear_guidance:
                 self._guidance_scale = guidance_scale_list[unit_index]
                 self._video_guidance_scale = guidance_scale_list[unit_index]
+            xs = [x[b, :, unit_index:unit_index + 1].contiguous() for b in range(nb)]
             if unit_index == 0:
-                past = [[] for _ in range(n_st)]
-                outs = self.generate_one_unit(x[:, :1].contiguous(), past, pm, pp, num_inference_steps, True)
+                pasts = [[[] for _ in range(n_st)] for _ in range(nb)]
+                outs = self._one_unit_batch(xs, pasts, ctxs, num_inference_steps, True)
             else:
-                clean = self._pyramid(torch.cat(generated, dim=1), n_st - 1)
-                past = self._history(clean, unit_index)
-                outs = self.generate_one_unit(x[:, unit_index:unit_index + 1].contiguous(), past, pm, pp,
-                                              video_num_inference_steps, False)
-            generated.append(outs[-1])
-        gen = torch.cat(generated, dim=1)[None]                                      # [1,C,T,h,w] fp32
+                pasts = [self._history(self._pyramid(torch.cat(generated[b], dim=1), n_st - 1), unit_index)
+                         for b in range(nb)]
+                outs = self._one_unit_batch(xs, pasts, ctxs, video_num_inference_steps, False)
+            for b in range(nb):
+                generated[b].append(outs[b][-1])
+        gen = torch.stack([torch.cat(g_, dim=1) for g_ in generated])                # [B,C,T,h,w] fp32
         if output_type == "latent":
             return gen.to(pe.dtype) if self._round else gen
         return self.decode_latent(gen, save_memory=save_memory, inference_multigpu=inference_multigpu,
@@ -327,6 +358,10 @@ class PyramidDiTForVideoGeneration:
             return None
         if self.vae is None:
             raise RuntimeError("VAE not loaded")
+        if latents.shape[0] > 1:            # "B C T H W -> (B T) H W C" (:1239): the samples decode one after another
+            parts = [self.decode_latent(latents[b:b + 1], save_memory, inference_multigpu, "uint8")
+                     for b in range(latents.shape[0])]
+            return self._finish_frames(None if parts[0] is None else torch.cat(parts, dim=0), output_type)
         z = latents.to(self._device, torch.float32)
         # un-normalisation (:1226-1230) is folded into the latent -> channels-last load of the decoder
         aff = (1.0 / self.vae_scale_factor, self.vae_shift_factor,

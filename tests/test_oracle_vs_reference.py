@@ -362,3 +362,16 @@ def test_bf16_trajectory_fixture_is_the_references(ref, tmp_path, monkeypatch):
     assert fresh["latents"].dtype == torch.bfloat16
     assert torch.equal(fresh["latents"], committed["latents"])
     assert torch.equal(fresh["prompt_embeds"], committed["prompt_embeds"])
+
+
+def test_batch_fixture_is_the_references_and_rows_are_independent(ref, tmp_path, monkeypatch):
+    """tests/golden/generate_tiny_latents_batch2.pt (two prompts through the reference's generate()) is reproduced bit
+    for bit; its two samples differ (two prompts, two rows of one random stream)."""
+    import os
+    from oracle import gen_golden as gg
+    committed = torch.load(os.path.join(gg.OUT, "generate_tiny_latents_batch2.pt"))
+    monkeypatch.setattr(gg, "OUT", str(tmp_path))
+    gg.generate_batch_fixture()
+    fresh = torch.load(os.path.join(str(tmp_path), "generate_tiny_latents_batch2.pt"))
+    assert torch.equal(fresh["latents"], committed["latents"])
+    assert fresh["latents"].shape[0] == 2 and not torch.equal(fresh["latents"][0], fresh["latents"][1])

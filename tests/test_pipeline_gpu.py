@@ -106,3 +106,32 @@ def test_generate_bf16_trajectory_vs_reference_fixture():
     print("bf16 trajectory rel-L2 per unit vs reference fixture:", [f"{e:.3e}" for e in per_unit])
     assert max(per_unit) < 5e-2
     assert rel_l2(lat.float().cpu(), ref) < 5e-2
+
+
+def test_generate_prompt_batch_vs_reference_fixture():
+    """a list of two prompts (pyramid_dit_for_video_gen_pipeline.py:1049-1053): latents and block noise are drawn with batch
+    shape from one stream, every sample runs under its own [negative | positive] context; each sample against the
+    reference's own batched run.  num_images_per_prompt = 2 on one prompt: two samples of that prompt, the first equal to
+    the batch's first sample only in its prompt (other noise rows), so only shapes / finiteness / distinctness are checked."""
+    g = torch.load(os.path.join(os.path.dirname(GOLD), "generate_tiny_latents_batch2.pt"))
+    pipe, _, _ = _pipe(dict(g, vae_cfg=torch.load(GOLD)["vae_cfg"], vae_weight_seed=torch.load(GOLD)["vae_weight_seed"]))
+    kw = dict(height=g["height"], width=g["width"], temp=g["temp"], num_inference_steps=g["steps"],
+              video_num_inference_steps=g["video_steps"], guidance_scale=g["guidance"],
+              video_guidance_scale=g["video_guidance"])
+    lat = pipe.generate(prompt_embeds=(*g["pos"], *g["neg"]), generator=torch.Generator().manual_seed(g["latent_seed"]),
+                        output_type="latent", **kw)
+    assert lat.shape == g["latents"].shape and lat.shape[0] == 2
+    for b in range(2):
+        err = rel_l2(lat[b].float().cpu(), g["latents"][b])
+        print(f"sample {b}: trajectory rel-L2 vs the reference's batched run: {err:.3e}")
+        assert err < 5e-2
+    # frames of a batch come back as (B T) H W C
+    from oracle.ref_harness import NoiseStream
+    pipe.block_noise_fn = NoiseStream(g["noise_seed"]).block_noise
+    pipe.vae.enable_tiling()
+    one = tuple(t_[:1] for t_ in g["pos"]) + tuple(g["neg"])
+    fr = pipe.generate(prompt_embeds=one, num_images_per_prompt=2, generator=torch.Generator().manual_seed(3),
+                       output_type="uint8", **kw)
+    T = 1 + 8 * (g["temp"] - 1)
+    assert fr.shape == (2 * T, g["height"], g["width"], 3) and fr.dtype == torch.uint8
+    assert not torch.equal(fr[:T], fr[T:])
