@@ -56,18 +56,27 @@ typedef struct {
      * double blocks, flux_block.py:816-835 / 42-100, and the prompt encoders): with it the K range is split over
      * ceil(256 / tiles) workgroups per tile (fp32 partial sums [split][batch][M][N] in the scratch, summed in split order
      * by a second launch that applies the epilogue), which turns one workgroup's chain of K / 64 dependent memory
-     * latencies into several short ones.  NULL / 0 = never split.  Must not be shared by launches that may overlap. */
+     * latencies into several short ones.  NULL / 0 = never split.  Must not be shared by launches that may overlap.
+     * LARGE problems (the persistent 256 x 256 kernel, pf_gemm_which == 8) use the same scratch, when it holds 64 MiB
+     * (pf_gemm_workspace_bytes), to split the tiles that do not fill a last round of the 256 workgroups along K: the
+     * parts park raw fp32 sums (one 256-KiB slot per workgroup), a second small launch adds them in part order and
+     * applies the epilogue -- the DiT's N = 1920, K = 7680 / 9600 projections otherwise run e.g. 1.25 "rounds" as 2.
+     * Bitwise repeatable; differs from the scratch-less result in fp32 summation order only. */
     void* workspace;
     long long workspace_bytes;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
+/* bytes of pf_gemm_desc.workspace this problem can use (0 = it never splits) */
+long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
 /* Kernel selection for pf_gemm_bf16 / pf_conv3d_bf16 (test hook; results are identical up to fp32 summation order).
  * 0 = automatic: the persistent 256 x 256 kernel (gemm8p) for problems of >= 192 such tiles whose N tail wastes < 7 %,
  * else the 256 x BN ping-pong kernel (BN = 256 / 192 / 128) when it yields >= 192 tiles, else the 128 x 128 kernel;
  * -1 = always the 128 x 128 kernel; 128 / 192 / 256 = force the 256 x BN kernel whenever BN divides N;
  * 8 = force gemm8p whenever its epilogue flavour exists (bias + ONE of residual / fp32 output / GELU-tanh); -8 = never
  * gemm8p; -2 / 2 = never / again split K for skinny problems that bring a workspace; -3 / 3 = never / again
- * the narrow-N conv kernel (3x3x3 convs with <= 8 output channels: the decoder's conv_out).  Default 0. */
+ * the narrow-N conv kernel (3x3x3 convs with <= 8 output channels: the decoder's conv_out); -4 / 4 = never / again
+ * split the tail tiles of gemm8p problems that bring a workspace; 400 + c (c = 0..199) = measurement hook: the split's
+ * assumed fixed cost in K-tile periods (default 4).  Default 0. */
 int pf_gemm_set_policy(int force);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =
  * gemm8p_kernel, BN > 0 = gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */

@@ -264,7 +264,10 @@ int pf_set_err(const char* m);
 #define set_err pf_set_err
 int pf_gemm256_pick(long long M_total, int M, int batch, int N, int force);
 int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, hipStream_t stream);
-int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream);      // gemm8p.hip: persistent 256 x 256 tiles
+int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream, void* ws, long long ws_bytes);   // gemm8p.hip: persistent 256 x 256 tiles
+void pf_gemm8p_set_tail_split(bool on);
+void pf_gemm8p_set_tail_overhead(int k_tiles);
+long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
 int pf_conv_narrow_launch(const pf_conv_desc* d, hipStream_t stream);
@@ -291,12 +294,27 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 8 || force == -8) { g_gemm8p_mode = force > 0 ? 1 : -1; g_gemm256_force = 0; return 0; }
     if (force == 2 || force == -2) { g_splitk_enabled = force > 0; return 0; }
     if (force == 3 || force == -3) { g_narrow_enabled = force > 0; return 0; }
+    if (force == 4 || force == -4) { pf_gemm8p_set_tail_split(force > 0); return 0; }
+    if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 3, -3, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 3, -3, 4, -4, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
+    pf_gemm8p_set_tail_split(true);
     return 0;
+}
+// Scratch that pays for this problem (pf_gemm_desc.workspace): 0 = none is used.  Large problems on the persistent 256 x 256
+// kernel split their tail tiles along K with one 256-KiB slot per workgroup; skinny problems split K over ~256 workgroups.
+extern "C" long long pf_gemm_workspace_bytes(int M, int batch, int N, int K) {
+    if (M <= 0 || batch <= 0 || N <= 0 || K <= 0) return 0;
+    if (use_gemm8p(M, batch, N, K)) return pf_gemm8p_workspace_bytes();
+    if (pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force())) return 0;
+    const int grid = (N / BN) * ((M + BM - 1) / BM) * batch, nk = K / BK;
+    if (grid >= 128 || nk < 8 || N % BN) return 0;
+    int ks = (256 + grid - 1) / grid;
+    ks = ks < nk / 4 ? ks : nk / 4;
+    return ks > 1 ? (long long)ks * batch * M * N * 4 : 0;
 }
 extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>
     if (use_gemm8p(M, batch, N, K)) return 8;
@@ -322,7 +340,7 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!g8 && !bn256 && d->N % BN != 0)
         return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (g8) {
-        pf_gemm8p_launch(a, false, stream);
+        pf_gemm8p_launch(a, false, stream, d->workspace, d->workspace_bytes);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
         return 0;
@@ -380,7 +398,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
     if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) {
-        pf_gemm8p_launch(a, true, stream);
+        pf_gemm8p_launch(a, true, stream, nullptr, 0);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
         return 0;

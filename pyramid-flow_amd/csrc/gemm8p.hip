@@ -20,6 +20,14 @@
 //     stay in flight across the barriers.  Invariant: at the end of load slot g (before its barrier) a wave's pieces
 //     of all units <= g+2 have landed; slot g reads units <= g+1; unit j+8 (same LDS region as unit j) is issued in
 //     slot j+2, two slots after the last read of unit j.
+//   * TAIL SPLIT (round 3): the r tiles of an XCD's chunk that do not fill a last round of its nslot workgroups are split
+//     along K into sp equal ranges each (sp * r <= nslot), when the caller brings scratch (pf_gemm_desc.workspace,
+//     64 MiB): a workgroup's last segment is then a K range of a tail tile, whose raw fp32 sums it parks in its 256-KiB
+//     slot, and a second small launch (gemm8p_tail_kernel) adds the parts in part order and applies the epilogue.  The
+//     parts of all tail tiles cover the SAME K ranges at the same time: the workgroups of an XCD keep reading operand
+//     panels in phase (a stream-K cut of the tail into 32 equal pieces that straddle tile boundaries was measured 5-15 %
+//     slower than this on the K = 9600 GEMMs: panels are then fetched from L2 at 32 different K offsets).
+//     Over one video the DiT's N = 1920 / K = 7680-9600 GEMMs ran at 0.72 of a whole number of rounds.
 // LDS: 2 K-tile buffers x (A 256 x 64 + W 256 x 64) bf16 = 128 KiB, XOR-swizzled like gemm256.hip (swizzle on the DMA
 // source address and on the ds_read_b128 address).
 #include "common.h"
@@ -47,6 +55,24 @@ constexpr int GROUP_M = 4;
     } while (0)
 
 struct TileCoord { int b, m0, n0; };
+
+// How the `clen` tiles of one XCD's chunk are dealt to its `nslot` workgroups: n_full whole rounds, then r tail tiles, each
+// split along K over sp workgroups (sp = 1: one whole tile for each of the first r workgroups, the round-2 behaviour):
+// workgroup s computes part s % sp of tail tile s / sp, K-tiles [q nk / sp, (q + 1) nk / sp).
+// The split pays when a part + the cost of parking and re-adding (a fixed `ov` K-tile periods: the second launch, its
+// kernel boundary, the 256-KiB park; + 0.6 per part: the second launch reads r * sp * 8 parts of 256 KiB) is shorter than
+// a whole tile.  Same function on the host (launch geometry of the second kernel) and in both kernels.
+struct TailPlan { int n_full, r, sp; };
+__host__ __device__ inline TailPlan tail_plan(int clen, int nslot, int nk, int ov) {
+    TailPlan t{clen / nslot, clen % nslot, 1};
+    if (ov < 0 || t.r == 0 || 2 * t.r > nslot || nk < 8) return t;
+    int best = 10 * nk;
+    for (int sp = 2; sp * t.r <= nslot && nk / sp >= 4; ++sp) {
+        const int cost = 10 * ((nk + sp - 1) / sp) + 10 * ov + 6 * sp * t.r;
+        if (cost < best) { best = cost; t.sp = sp; }
+    }
+    return t;
+}
 
 PF_DEVICE TileCoord tile_coord(const Args& p, int t, int tiles_m, int tiles_n) {
     const int TM = tiles_m * p.batch;
@@ -80,10 +106,27 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     const int cq = T >> 3, cr = T & 7;
     const int cs = xcd * cq + min(xcd, cr);
     const int clen = cq + (xcd < cr ? 1 : 0);
-    const int n_my = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;
-    if (n_my == 0) return;
     const int nk = p.K / BK;
-    const int U = 4 * nk * n_my;                    // 16-KiB units of the operand stream (A0, B0, B1, A1 per K-tile)
+    // segments of this workgroup: n_full whole tiles, then at most one tail segment = K-tiles [tail_k0, tail_k1) of tile
+    // `tail_tile` (a whole tile unless the tail is split: tail_plan)
+    const TailPlan tp = tail_plan(clen, nslot, nk, (!CONV && p.part != nullptr && (nwg & 7) == 0) ? p.tail_ov : -1);
+    // (CONV: ov = -1 is a compile-time constant, the plan folds to { n_full, r, 1 } and the split code disappears)
+    int tail_tile = -1, tail_k0 = 0, tail_k1 = 0;
+    if (tp.sp > 1) {
+        const int j = slot / tp.sp, q = slot - j * tp.sp;
+        if (j < tp.r) { tail_tile = cs + tp.n_full * nslot + j; tail_k0 = q * nk / tp.sp; tail_k1 = (q + 1) * nk / tp.sp; }
+    } else if (slot < tp.r) {
+        tail_tile = cs + tp.n_full * nslot + slot; tail_k1 = nk;
+    }
+    const bool tail_parks = tp.sp > 1;              // the tail segment ends with raw sums in scratch, not with an epilogue
+    const int n_full = tp.n_full;
+    const int n_my = n_full + (tail_tile >= 0 ? 1 : 0);
+    if (n_my == 0) return;
+    auto tile_of = [&](int seq) { return seq < n_full ? cs + slot + seq * nslot : tail_tile; };
+    auto seg_begin = [&](int seq) { return seq < n_full ? 0 : tail_k0; };
+    auto seg_end = [&](int seq) { return seq < n_full ? nk : tail_k1; };
+    const int GK = n_full * nk + (tail_k1 - tail_k0);      // K-tiles of all segments
+    const int U = 4 * GK;                           // 16-KiB units of the operand stream (A0, B0, B1, A1 per K-tile)
 
     // ---- DMA geometry.  A unit = 16 pieces of 8 LDS rows; wave w owns pieces 2w, 2w+1 of every unit.
     //   A sub s (s = 0,1): LDS rows wm'*128 + s*64 + [0,64) for wm' = 0,1   (natural row order)
@@ -105,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 
     // ---- issue-side state: (tile, K-tile) of the unit group being issued, per-lane byte offsets relative to the
     //      tile's scalar base pointers
-    int is_tile = 0, is_kt = 0;
+    int is_tile = 0, is_kt = 0, is_kt_end = nk;
     const char* is_abase = nullptr;                 // A + batch/tile offset (bytes), wave-uniform
     const char* is_wbase = nullptr;
     unsigned a_off[2][2], w_off[2][2];
@@ -113,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     int is_c0 = 0, is_dw = 0, is_dh = 0, is_dt = 0;
 
     auto setup_issue_tile = [&](int seq) {
-        const TileCoord tc = tile_coord(p, cs + slot + seq * nslot, tiles_m, tiles_n);
+        const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
         const bf16_t* A = p.A + (long long)tc.b * p.sA;
         long long base_el;                          // element offset of the tile's first row
         if (CONV) {
@@ -149,7 +192,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                 n = n < p.N ? n : p.N - 1;
                 w_off[s][e] = (unsigned)((long long)(n - tc.n0) * p.ldw * 2 + (((ln & 7) ^ ((rb >> 1) & 7)) << 4));
             }
-        is_kt = 0;
+        is_kt = seg_begin(seq);                     // (a start inside K only happens without CONV: tail split)
+        is_kt_end = seg_end(seq);
         is_c0 = is_dw = is_dh = is_dt = 0;
     };
 
@@ -183,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     if (++is_dw == p.cg.kw) { is_dw = 0; if (++is_dh == p.cg.kh) { is_dh = 0; ++is_dt; } }
                 }
             }
-            if (is_kt == nk) {
+            if (is_kt == is_kt_end) {
                 ++is_tile;
                 if (is_tile < n_my) setup_issue_tile(is_tile);
             }
@@ -208,10 +252,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     // (the residual flavour has no registers to spare for this: it starts from zero and adds the bias in its epilogue)
     constexpr bool FOLD_BIAS = (EPI & 1) == 0;
     auto load_bias = [&](int seq) {
-        const TileCoord tc = tile_coord(p, cs + slot + seq * nslot, tiles_m, tiles_n);
+        const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
         const f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         nb0 = nb1 = nb2 = nb3 = z;
-        if (FOLD_BIAS && p.bias) {
+        // (the parts of a split tail tile start from zero: gemm8p_tail_kernel adds the bias)
+        if (FOLD_BIAS && p.bias && !(tail_parks && seq >= n_full)) {
             const int c0 = tc.n0 + wn * 64 + 8 * fq, c1 = c0 + 32;
             const float* b0 = p.bias + (c0 < p.n_valid ? c0 : 0);
             const float* b1 = p.bias + (c1 < p.n_valid ? c1 : 0);
@@ -266,8 +311,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     //      Order: request bias / gate / the residual pieces, drain the vector-memory queue ONCE (this also retires
     //      every DMA issued so far, see the main loop), then fp32 math and one 16-byte store per (row fragment, half).
     constexpr bool E_RES = (EPI & 1) != 0, E_F32 = (EPI & 2) != 0, E_ACT = (EPI & 4) != 0;
-    auto epilogue = [&](int seq) {
-        const TileCoord tc = tile_coord(p, cs + slot + seq * nslot, tiles_m, tiles_n);
+    auto epilogue_tile = [&](int seq) {
+        const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
         const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
         const bool mapped = CONV && p.om.mode == 1;
         // output element offset of (row m, column n); false = nothing to store for this row
@@ -421,8 +466,24 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     PF_FENCE();
                 }
         }
-        // the accumulators restart (from the next tile's bias) only now: re-initialising them while the packed results
-        // are still waiting for their stores would keep 128 + 64 registers alive at once
+    };
+    // part of a split tail tile (always this workgroup's last segment): park the raw sums, lane-linear 16-byte pieces,
+    // piece = accumulator index (row fragment f, column group c): slot `bid`, 32 KiB per wave
+    auto park = [&]() {
+        int lnp = lane;
+        asm volatile("" : "+v"(lnp));
+        char* const pw = (char*)p.part + ((long long)bid * 8 + wid) * 32768 + (unsigned)lnp * 16u;
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) *(f32x4v*)(pw + (f * 4 + c) * 1024) = acc[f][c];
+    };
+    auto epilogue = [&](int seq) {
+        if (!CONV && tail_parks && seq >= n_full) { park(); return; }
+        epilogue_tile(seq);
+        // the accumulators restart (from the next tile's bias; zero after / before a parked segment) only now:
+        // re-initialising them while the packed results are still waiting for their stores would keep 128 + 64 registers
+        // alive at once
         PF_FENCE();
         acc_from_bias();
     };
@@ -456,8 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         PF_FENCE();
     };
 
-    int c_tile = 0, c_kt = 0;
-    const int GK = nk * n_my;
+    int c_tile = 0, c_kt = seg_begin(0), c_end = seg_end(0);
     for (int gk = 0; gk < GK; ++gk) {
         const int bs = gk & 1;
         const int g = 4 * gk;
@@ -481,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         // phase 3: no fragment reads (B sub 0 is still resident) | (A1, B0)
         end_of_load_slot(g + 3);
         mfma_quadrant(1, 0);
-        if (++c_kt == nk) {
+        if (++c_kt == c_end) {
             // every DMA issued so far has had >= one MFMA slot; draining here makes the waits of the next four load
             // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
             // epilogue out of the counted waits
@@ -489,18 +549,94 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             epilogue(c_tile);
             PF_FENCE();
             skip_wait = 4;
-            c_kt = 0;
             ++c_tile;
+            c_kt = seg_begin(c_tile);
+            c_end = seg_end(c_tile);
         }
         PF_BAR();
     }
     if (wm == 0) PF_BAR();                 // matches group 1's extra barrier
 }
 
+// Second launch of a GEMM whose tail tiles were split along K: C = epi(sum over the parts, in part order, of the parked
+// fp32 sums) for those tiles only.  32 blocks per tail tile; a thread owns what a lane of the main kernel owns for one
+// (row fragment, column half): 8 consecutive columns of one row.  p.ksplit = the main launch's workgroup count.
+__global__ __launch_bounds__(256) void gemm8p_tail_kernel(const Args p) {
+    const int chunk = blockIdx.x & 31, tj = blockIdx.x >> 5;
+    const int xcd = tj & 7, j = tj >> 3;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int T = tiles_m * p.batch * tiles_n;
+    const int nwg = p.ksplit;
+    const int nslot = (nwg - xcd + 7) >> 3;
+    const int cq = T >> 3, cr = T & 7;
+    const int cs = xcd * cq + min(xcd, cr);
+    const int clen = cq + (xcd < cr ? 1 : 0);
+    const int nk = p.K / BK;
+    const TailPlan tp = tail_plan(clen, nslot, nk, p.tail_ov);
+    if (tp.sp <= 1 || j >= tp.r) return;
+    const TileCoord tc = tile_coord(p, cs + tp.n_full * nslot + j, tiles_m, tiles_n);
+    const int lane = threadIdx.x & 63;
+    const int item = chunk * 4 + (threadIdx.x >> 6);            // (wave 0..7, row fragment 0..7, column half 0..1)
+    const int w = item >> 4, f = (item >> 1) & 7, hsel = item & 1;
+    const int m = tc.m0 + (w >> 2) * 128 + 16 * f + (lane & 15);
+    const int n = tc.n0 + (w & 3) * 64 + 32 * hsel + 8 * (lane >> 4);
+    if (m >= p.M || n >= p.n_valid) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    // part q of tile j was parked by workgroup (slot j sp + q, this XCD); four parts' loads are in flight at a time and
+    // the sums are added in part order
+    const char* const src0 = (const char*)p.part + ((long long)((j * tp.sp) * 8 + xcd) * 8 + w) * 32768 +
+                             (f * 4 + 2 * hsel) * 1024 + lane * 16;
+    constexpr long long PART_STRIDE = 8ll * 8 * 32768;          // next workgroup slot of the same XCD
+    int q = 0;
+    for (; q + 4 <= tp.sp; q += 4) {
+        f32x4_t a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0[u] = *(const f32x4_t*)(src0 + (q + u) * PART_STRIDE);
+            a1[u] = *(const f32x4_t*)(src0 + (q + u) * PART_STRIDE + 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += a0[u][e]; v[4 + e] += a1[u][e]; }
+    }
+    for (; q < tp.sp; ++q) {
+        const f32x4_t v0 = *(const f32x4_t*)(src0 + q * PART_STRIDE), v1 = *(const f32x4_t*)(src0 + q * PART_STRIDE + 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += v0[e]; v[4 + e] += v1[e]; }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+    }
+    if (n >= p.gelu_from) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+    }
+    const long long coff = (long long)tc.b * p.sC + (long long)m * p.ldc + n;
+    if (p.flags & PF_GEMM_GATE_RES) {
+        float rv[8];
+        unpack8(*(const u32x4_t*)(p.res + (long long)tc.b * p.sR + (long long)m * p.ldr + n), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rv[e] + (p.gate ? p.gate[(long long)tc.b * p.gate_stride + n + e] : 1.f) * v[e];
+    }
+    if (p.flags & PF_GEMM_OUT_F32) {
+        float* c = (float*)p.C + coff;
+        *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
+    } else {
+        *(u32x4_t*)((bf16_t*)p.C + coff) = pack8(v);
+    }
+}
+
 int g_num_cu = 0;
+bool g_tail_split = true;                  // pf_gemm_set_policy(-4) / (4): never / again split the tail tiles along K
+int g_tail_ov = 4;                         // fixed cost of a split in K-tile periods (tail_plan; pf_gemm_set_policy(400 + ov))
 
 template <bool CONV, int EPI>
-int launch(const Args& a, hipStream_t stream) {
+int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
     PF_SET_MAX_LDS_ONCE((gemm8p_kernel<CONV, EPI>), SMEM);
     if (!g_num_cu) {
         int dev = 0;
@@ -508,9 +644,25 @@ int launch(const Args& a, hipStream_t stream) {
         hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (g_num_cu <= 0) g_num_cu = 256;
     }
+    Args a = a_in;
     const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
     const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    // tail split: one 256-KiB slot of caller scratch per workgroup; the second launch covers the XCD with the most tail tiles
+    a.part = nullptr;
+    a.ksplit = grid;
+    a.tail_ov = g_tail_ov;
+    int rmax = 0;
+    if (!CONV && g_tail_split && ws && (grid & 7) == 0 && ws_bytes >= (long long)grid * (256 << 10)) {
+        const int nk = a.K / BK, nslot = grid >> 3;
+        for (int xcd = 0; xcd < 8; ++xcd) {
+            const int clen = (tiles >> 3) + (xcd < (tiles & 7) ? 1 : 0);
+            const TailPlan tp = tail_plan(clen, nslot, nk, g_tail_ov);
+            if (tp.sp > 1 && tp.r > rmax) rmax = tp.r;
+        }
+        if (rmax > 0) a.part = (float*)ws;
+    }
     hipLaunchKernelGGL((gemm8p_kernel<CONV, EPI>), dim3(grid), dim3(512), SMEM, stream, a);
+    if (rmax > 0) hipLaunchKernelGGL(gemm8p_tail_kernel, dim3(rmax * 8 * 32), dim3(256), 0, stream, a);
     return 0;
 }
 
@@ -528,12 +680,18 @@ bool pf_gemm8p_supports(const Args& a, bool conv) {
     return true;
 }
 
-int pf_gemm8p_launch(const Args& a_in, bool conv, hipStream_t stream) {
+void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }
+void pf_gemm8p_set_tail_overhead(int k_tiles) { g_tail_ov = k_tiles; }
+
+// Scratch (bytes) with which pf_gemm8p_launch may split the tail tiles of a problem along K (one slot per workgroup).
+long long pf_gemm8p_workspace_bytes() { return 256ll * (256 << 10); }
+
+int pf_gemm8p_launch(const Args& a_in, bool conv, hipStream_t stream, void* ws, long long ws_bytes) {
     const Args& a = a_in;
     const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
-    if (conv) return launch<true, 0>(a, stream);          // conv + shortcut add stays on gemm256 (pf_gemm8p_supports)
-    if (res) return launch<false, 1>(a, stream);
-    if (f32) return launch<false, 2>(a, stream);
-    if (act) return launch<false, 4>(a, stream);
-    return launch<false, 0>(a, stream);
+    if (conv) return launch<true, 0>(a, stream, nullptr, 0);   // conv + shortcut add stays on gemm256 (pf_gemm8p_supports)
+    if (res) return launch<false, 1>(a, stream, ws, ws_bytes);
+    if (f32) return launch<false, 2>(a, stream, ws, ws_bytes);
+    if (act) return launch<false, 4>(a, stream, ws, ws_bytes);
+    return launch<false, 0>(a, stream, ws, ws_bytes);
 }

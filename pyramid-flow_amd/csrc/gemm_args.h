@@ -36,6 +36,8 @@ struct Args {
     int group_m;             // M-tiles per L2 super-tile of the 256-row kernels (tile order; 0 = default)
     int ksplit;              // 128 x 128 kernel: workgroups per output tile along K (0 / 1 = none); > 1 writes raw fp32
     float* part;             //   partial sums part[((s * batch + b) * M + m) * N + n] instead of running the epilogue
+                             // gemm8p: ksplit = workgroups of the main launch, part = scratch of the tail split (parked sums),
+    int tail_ov;             //   tail_ov = the split's fixed cost in K-tile periods (gemm8p.hip: tail_plan)
     ConvGeom cg; OutMap om;
 };
 

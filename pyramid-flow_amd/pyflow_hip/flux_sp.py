@@ -102,6 +102,7 @@ class FluxEngineSP(FluxEngine):
             # scratch of the text rows' skinny GEMMs: same K split as the single-process engine (one 128-row tile per
             # prompt either way), hence the same fp32 summation order and bit-identical text rows
             ws_txt=self._buf("splitk_txt", 8 << 20, torch.float32),
+            ws_img=self._buf("gemm_tail", 16 << 20, torch.float32),      # 64 MiB: tail split of the large GEMMs
             tok=self._buf("tok", B * L_img * w.in_ch, bf),
             vtok=self._buf("vtok", B * n_cur * npad, torch.float32))
 
@@ -140,8 +141,8 @@ class FluxEngineSP(FluxEngine):
         lay = st["lay"]
         nloc, n_txt, n_img = lay.nloc, lay.n_txt, lay.n_img
         mh, mc = lay.my_heads, lay.my_cols
-        hidden, xn, big, send1, recv1, obuf, recv2, vT, ws_txt, vtok = (st[k] for k in (
-            "hidden", "xn", "big", "send1", "recv1", "obuf", "recv2", "vT", "ws_txt", "vtok"))
+        hidden, xn, big, send1, recv1, obuf, recv2, vT, ws_txt, ws_img, vtok = (st[k] for k in (
+            "hidden", "xn", "big", "send1", "recv1", "obuf", "recv2", "vT", "ws_txt", "ws_img", "vtok"))
         nm = w.n_mod
         Ld, L3, L4, L7 = nloc * d, nloc * 3 * d, nloc * 4 * d, nloc * 7 * d
         mlp_base = B * L3
@@ -187,7 +188,7 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 6 * d, mb + 7 * d)
             if n_img:
                 ops.gemm(xn, blk["kvq_img"][0], big, n_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d)
+                         strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, workspace=ws_img)
             if n_txt:
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
                          strideA=Ld, strideC=L3, workspace=ws_txt)
@@ -198,7 +199,7 @@ class FluxEngineSP(FluxEngine):
             if n_act > 0:
                 ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d, workspace=ws_img)
             if n_txt and not pre_only:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
@@ -208,11 +209,11 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
             if n_act > 0:
                 ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
-                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d)
+                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d, workspace=ws_img)
                 ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                          res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + i0 * 4 * d, c_off=i0 * d,
-                         r_off=i0 * d)
+                         r_off=i0 * d, workspace=ws_img)
             if n_txt and not pre_only:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
@@ -233,13 +234,13 @@ class FluxEngineSP(FluxEngine):
             # K|V|Q first, then the MLP branch (proj_mlp + GELU, flux_block.py:921-922) while the exchanges fly
             if nloc:
                 ops.gemm(xn, blk["kvqm"][0], big, nloc, 3 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7)
+                         strideC=L7, workspace=ws_img)
 
             def mlp_cols(c0, nc, blk=blk, i0=i0, n_act=n_act):
                 if n_act > 0 and nc > 0:
                     ops.gemm(xn, blk["kvqm"][0], big, n_act, nc, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B,
                              strideA=Ld, strideC=L7, gelu_from=0, a_off=i0 * d, w_off=(3 * d + c0) * d,
-                             c_off=i0 * 7 * d + 3 * d + c0, bias_off=3 * d + c0)
+                             c_off=i0 * 7 * d + 3 * d + c0, bias_off=3 * d + c0, workspace=ws_img)
             norms = (blk["norm_q"], blk["norm_k"], None, None)
             attend(7 * d, norms, overlap=lambda: mlp_cols(0, n1), q_row_begin=r_cur if last else 0)
             h2 = self._exchange_out_start(lay, obuf, B, recv2)
@@ -248,7 +249,7 @@ class FluxEngineSP(FluxEngine):
             if n_act > 0:
                 ops.gemm(big, blk["out"][0], hidden, n_act, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 7 * d + 2 * d, c_off=i0 * d, r_off=i0 * d)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 7 * d + 2 * d, c_off=i0 * d, r_off=i0 * d, workspace=ws_img)
         if debug is not None:
             debug["hidden_final_local"] = hidden[:B * nloc * d].view(B, nloc, d).clone()
 

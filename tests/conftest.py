@@ -22,3 +22,17 @@ def pytest_collection_modifyitems(config, items):
         for it in items:
             if "reference" in it.keywords:
                 it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory_between_tests(request):
+    """GPU tests that spawn rank processes on the SAME device (tests/test_sp_gpu.py, test_bench_selflaunch_gpu.py: up to
+    ~75 GiB per rank) need the memory this process's caching allocator still holds from earlier tests: hand it back to the
+    driver after every GPU test (the full-depth / 768p tests leave > 200 GiB cached otherwise and a later rank runs out)."""
+    yield
+    if "gpu" in request.keywords:
+        import gc
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            gc.collect()
+            torch.cuda.empty_cache()

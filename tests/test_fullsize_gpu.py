@@ -114,7 +114,21 @@ def test_full_size_forward_invariants():
     eng.skip_dead_rows = False
     eng.overlap_text = False
     v3 = eng.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True).clone()
-    assert torch.equal(v1, v3)
+    # the last block's GEMMs have other row counts without the restriction -> other tail splits of the persistent kernel
+    # (round 3) -> another fp32 summation order: equal to rounding, and ...
+    assert rel_l2(v3.cpu(), v1.cpu()) < 2e-3
+    # ... bit for bit with the tail split switched off (whole tiles only: the value of a row does not depend on M)
+    from pyflow_hip import ops
+    ops.gemm_set_policy(-4)
+    try:
+        a = eng.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True).clone()
+        eng.skip_dead_rows = True
+        eng.overlap_text = True
+        b = eng.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True).clone()
+    finally:
+        ops.gemm_set_policy(4)
+    assert torch.equal(a, b)
+    assert rel_l2(a.cpu(), v1.cpu()) < 2e-3
     del eng
     torch.cuda.empty_cache()
     sp = _full_engine(FluxEngineSP)

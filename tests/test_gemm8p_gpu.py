@@ -147,3 +147,137 @@ def test_vae_decode_with_gemm8p(policy8):
     vae = CausalVideoVAE(sd, cfg, "cuda")
     out = vae.decode(z.cuda(), temporal_chunk=True, window_size=1).sample.float().cpu()
     assert rel_l2(out, ref) < 2e-2
+
+
+# ---- round 3: tail split (the tiles that do not fill a last round of the workgroups are split along K, parked as raw fp32
+#      sums in caller scratch and finished by gemm8p_tail_kernel)
+def _tail_plan(clen, nslot, nk, ov=4):
+    """python restatement of csrc/gemm8p.hip: tail_plan -> (n_full, r, sp); sp = 1: no split"""
+    n_full, r, sp = clen // nslot, clen % nslot, 1
+    if r == 0 or 2 * r > nslot or nk < 8:
+        return n_full, r, sp
+    best = 10 * nk
+    s_ = 2
+    while s_ * r <= nslot and nk // s_ >= 4:
+        cost = 10 * -(-nk // s_) + 10 * ov + 6 * s_ * r
+        if cost < best:
+            best, sp = cost, s_
+        s_ += 1
+    return n_full, r, sp
+
+
+def _splits(M, batch, N, K):
+    T = -(-M // 256) * batch * -(-N // 256)
+    assert T >= 256
+    return [_tail_plan(T // 8 + (1 if x < T % 8 else 0), 32, K // 64) for x in range(8)]
+
+
+def _is_split(plans):
+    return any(sp > 1 for _, _, sp in plans)
+
+
+@pytest.fixture
+def ws64():
+    n = ops_ws_bytes()
+    assert n == 64 << 20
+    return torch.empty(n // 4, dtype=torch.float32, device=DEV)
+
+
+def ops_ws_bytes():
+    from pyflow_hip import ops
+    return ops.L.load().pf_gemm_workspace_bytes(30976, 1, 1920, 1920)
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (10000, 1920, 7680),       # 320 tiles: every XCD 1 round + 8 tail tiles, each split along K (the MLP-down shape)
+    (9472, 1792, 1920),        # 259 tiles: three XCDs own one tail tile, five own none
+    (9472 + 77, 1920, 2560),   # M and N tails inside split tiles (304 tiles: r = 6, nk = 40)
+    (12 * 256, 6 * 256 * 4, 1920),   # 288 tiles: r = 4 per XCD
+    (20000, 1920, 9600),       # 2 rounds + 15 tiles: 2-way split of 150 K-tiles
+    (4208 * 2, 1920, 9600),    # 1 round + 2 tiles per XCD: many parts per tile (the 4-at-a-time loop of the second kernel)
+    (30976, 1920, 9600),       # the single blocks' proj_out at the longest sequence: 3 rounds + 25 tiles -> never split
+    (7000, 1920, 7680),        # 28 x 8 = 224 tiles < 256 workgroups: never split
+])
+def test_gemm8p_tail_split_bias(ws64, M, N, K):
+    from pyflow_hip import ops
+    assert ops.L.load().pf_gemm_which(M, 1, N, K) == 8
+    split = False
+    if M != 7000:
+        plans = _splits(M, 1, N, K)
+        split = _is_split(plans)
+        assert split == (M != 30976), plans
+    A = _mk((M, K), 1).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 2, 0.05).to(torch.bfloat16).to(DEV)
+    W[0, :] += 1.0
+    bias = _mk((N,), 3).to(DEV)
+    C = torch.zeros(M + 3, N, dtype=torch.bfloat16, device=DEV)
+    C0 = torch.zeros(M + 3, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, W, C, M, N, K, K, K, N, bias=bias, workspace=ws64)
+    ops.gemm(A, W, C0, M, N, K, K, K, N, bias=bias)                      # no scratch: whole tiles only
+    step = 4096
+    for r0 in range(0, M, step):
+        ref = A[r0:r0 + step].float() @ W.float().T + bias
+        assert rel_l2(C[r0:r0 + step][:M - r0].float(), ref[:M - r0]) < 5e-3
+        assert (C[r0:r0 + step][:M - r0].float() - ref[:M - r0]).abs().max() <= 2 ** -6 * ref.abs().max()
+    assert C[M:].abs().max() == 0
+    d = (C.float() - C0.float()).abs()
+    assert d.max() <= 2 ** -7 * C0.float().abs().max()                   # fp32 summation order only: <= one bf16 ulp
+    if split:
+        assert (d > 0).any()                                             # ... and the split really ran
+    else:
+        assert torch.equal(C, C0)
+    C2 = torch.zeros_like(C)
+    ops.gemm(A, W, C2, M, N, K, K, K, N, bias=bias, workspace=ws64)
+    assert torch.equal(C, C2)                                            # parts are added in part order: repeatable
+
+
+def test_gemm8p_tail_split_flavours(ws64):
+    """GELU from a column, gate * x + residual written in place, fp32 output; batch of 2 with strides and row offsets"""
+    from pyflow_hip import ops
+    d, B, Lr = 1920, 2, 4400
+    L = Lr + 16
+    assert _is_split(_splits(Lr, B, 2 * d, d)) and _is_split(_splits(Lr, B, d, 2 * d))
+    x = _mk((B, L, d), 4).to(torch.bfloat16).to(DEV)
+    W = _mk((2 * d, d), 5, 0.03).to(torch.bfloat16).to(DEV)
+    bias = _mk((2 * d,), 6, 0.1).to(DEV)
+    out = torch.zeros(B, L, 2 * d, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(x, W, out, Lr, 2 * d, d, d, d, 2 * d, bias=bias, batch=B, strideA=L * d, strideC=L * 2 * d,
+             gelu_from=d, a_off=16 * d, c_off=16 * 2 * d, workspace=ws64)
+    ref = x[:, 16:].float() @ W.float().T + bias
+    ref[..., d:] = F.gelu(ref[..., d:], approximate="tanh")
+    assert rel_l2(out[:, 16:].float(), ref) < 5e-3
+    assert out[:, :16].abs().max() == 0
+    hid = _mk((B, L, d), 7).to(torch.bfloat16).to(DEV)
+    hid0 = hid.clone()
+    W2 = _mk((d, 2 * d), 8, 0.03).to(torch.bfloat16).to(DEV)
+    b2 = _mk((d,), 9, 0.1).to(DEV)
+    gate = _mk((B, 3 * d), 10).to(DEV)
+    ops.gemm(out, W2, hid, Lr, d, 2 * d, 2 * d, 2 * d, d, bias=b2, res=hid, gate=gate, gate_off=d, ldr=d, batch=B,
+             strideA=L * 2 * d, strideC=L * d, strideR=L * d, gate_stride=3 * d, flags=ops.GEMM_GATE_RES,
+             a_off=16 * 2 * d, c_off=16 * d, r_off=16 * d, workspace=ws64)
+    ref2 = hid0[:, 16:].float() + gate[:, None, d:2 * d] * (out[:, 16:].float() @ W2.float().T + b2)
+    assert rel_l2(hid[:, 16:].float(), ref2) < 5e-3
+    assert torch.equal(hid[:, :16], hid0[:, :16])
+    Cf = torch.zeros(B, Lr, d, dtype=torch.float32, device=DEV)
+    ops.gemm(out, W2, Cf, Lr, d, 2 * d, 2 * d, 2 * d, d, bias=b2, batch=B, strideA=L * 2 * d, strideC=Lr * d,
+             flags=ops.GEMM_OUT_F32, a_off=16 * 2 * d, workspace=ws64)
+    assert rel_l2(Cf, out[:, 16:].float() @ W2.float().T + b2) < 1e-5
+
+
+def test_gemm8p_tail_split_policy_switch(ws64):
+    """pf_gemm_set_policy(-4): scratch is ignored and the result equals the launch without scratch bit for bit"""
+    from pyflow_hip import ops
+    M, N, K = 10000, 1920, 7680
+    A = _mk((M, K), 61).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 62, 0.03).to(torch.bfloat16).to(DEV)
+    C0, C1, C2 = (torch.zeros(M, N, dtype=torch.float32, device=DEV) for _ in range(3))
+    ops.gemm(A, W, C0, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32)
+    ops.gemm_set_policy(-4)
+    try:
+        ops.gemm(A, W, C1, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32, workspace=ws64)
+    finally:
+        ops.gemm_set_policy(4)
+    ops.gemm(A, W, C2, M, N, K, K, K, N, flags=ops.GEMM_OUT_F32, workspace=ws64)
+    assert torch.equal(C0, C1) and not torch.equal(C0, C2)
+    assert rel_l2(C2, C0) < 1e-6
+    assert ops.L.load().pf_gemm_workspace_bytes(M, 1, N, K) == 64 << 20
