@@ -106,8 +106,16 @@ typedef struct {
     int in_sh, in_sw;        /* input stride per output pixel in h / w (0 = 1): CausalDownsample2x of the encoder
                                 (modeling_resnet.py:291-336) reads X[... (h*in_sh+dh) ... (w*in_sw+dw) ...] */
     int in_st;               /* input frame stride per output frame (0 = 1): CausalTemporalDownsample2x (:458-502) */
+    /* optional: GroupNorm statistics of the OUTPUT accumulated by the conv's epilogue (CausalGroupNorm of the layer that
+     * reads Y: modeling_causal_conv.py:36-43), double [T][gn_C][2] = (sum, sum of squares) per output frame and channel,
+     * zeroed by the caller -- the layout pf_gn_stats writes, so pf_gn_apply can follow without a pf_gn_stats pass.
+     * Honoured only where pf_conv3d_fuses_gn_stats(desc) returns 1 (the 256-row kernel, plain output map, frames of a
+     * multiple of 256 pixels); otherwise ignored and the caller runs pf_gn_stats.  NULL = none. */
+    double* gn_stats;
+    int gn_C;
 } pf_conv_desc;
 int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
+int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d);   /* 1 = pf_conv3d_bf16(d) accumulates d->gn_stats */
 
 
 /* ------------------------------------------------------------------ attention --------------------

@@ -378,6 +378,23 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     return 0;
 }
 
+// GroupNorm statistics in the conv epilogue: only the 256-row ping-pong kernel at BN = 128 / 256 accumulates them, for a
+// plain output map (no pixel shuffle / depth-to-time / frame drop) whose frames are whole numbers of 256-pixel tiles
+static bool conv_fuses_gn_stats(const pf_conv_desc* d) {
+    if (!d->gn_stats || d->gn_C <= 0) return false;
+    if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->out_t_shift != 0 || (d->flags & PF_GEMM_OUT_F32)) return false;
+    if (((long long)d->H * d->W_) % 256 != 0) return false;
+    const int ntaps = d->kt * d->kh * d->kw;
+    const long long M = (long long)d->T * d->H * d->W_;
+    const int nv = d->n_valid > 0 ? d->n_valid : d->N;
+    if (nv > d->gn_C || M > 0x7fffffff) return false;
+    if (g_narrow_enabled && pf_conv_narrow_supports(d)) return false;
+    if (use_gemm8p((int)M, 1, d->N, ntaps * d->Cin) && nv % 8 == 0 && !(d->flags & PF_GEMM_GATE_RES)) return false;   // gemm8p conv
+    const int bn = pf_gemm256_pick(M, (int)M, 1, d->N, gemm256_force());
+    return bn == 128 || bn == 256;
+}
+extern "C" int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d) { return d && conv_fuses_gn_stats(d) ? 1 : 0; }
+
 extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     if (!d || !d->X || !d->W || !d->Y) return set_err("pf_conv3d_bf16: null operand");
     const int ntaps = d->kt * d->kh * d->kw;
@@ -397,6 +414,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
                     d->in_sh > 0 ? d->in_sh : 1, d->in_sw > 0 ? d->in_sw : 1, d->in_st > 0 ? d->in_st : 1};
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
+    if (conv_fuses_gn_stats(d)) { a.gn_stats = d->gn_stats; a.gn_C = d->gn_C; }
     if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) {
         pf_gemm8p_launch(a, true, stream, nullptr, 0);
         hipError_t e2 = hipGetLastError();

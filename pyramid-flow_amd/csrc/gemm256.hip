@@ -234,6 +234,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
     constexpr int CG = BN / 16;                 // 8-column groups per staged row
     const int wave_m0 = m0 + g * 128 + wm * 64;
     const int wave_n0 = n0 + wn * (BN / 2);
+    // GroupNorm statistics of the stored output (conv only, p.gn_stats): a lane owns the same 8 columns in every item
+    // (64 % CG == 0), so it sums its rows in registers; lanes -> waves -> one double atomic per (column, statistic) and tile
+    constexpr bool STATS = CONV && (64 % CG == 0);
+    const bool do_stats = STATS && p.gn_stats != nullptr;
+    float gs[8], gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -306,10 +313,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
                 *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
                 *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
             } else {
-                *(u32x4_t*)((bf16_t*)p.C + coff) = pack8(v);
+                const u32x4_t packed = pack8(v);
+                *(u32x4_t*)((bf16_t*)p.C + coff) = packed;
+                if (STATS) {
+                    if (do_stats) {               // statistics of the values as stored (what pf_gn_stats would read back)
+                        float sv[8];
+                        unpack8(packed, sv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { gs[e] += sv[e]; gq[e] += sv[e] * sv[e]; }
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (STATS) {
+        if (do_stats) {                            // workgroup-uniform
+#pragma unroll
+            for (int off = CG; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gs[e] += __shfl_xor(gs[e], off, 64);
+                    gq[e] += __shfl_xor(gq[e], off, 64);
+                }
+            if (lane < CG) {                       // the wave's sums of columns wave_n0 + 8 lane + e over its 64 rows
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    st[(lane * 8 + e) * 2] = gs[e];
+                    st[(lane * 8 + e) * 2 + 1] = gq[e];
+                }
+            }
+            PF_BARRIER();
+            if (tid < 2 * BN) {
+                const int c = tid >> 1, k = tid & 1;
+                const int wn_ = c / (BN / 2), cc = c - wn_ * (BN / 2);
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) sum += ((const float*)(smem + (wn_ + 2 * w) * C_::EPI_BYTES))[cc * 2 + k];
+                const int n = n0 + c;
+                if (n < p.n_valid && m0 < p.M) {
+                    const int frame = m0 / (p.om.H * p.om.W);      // a tile lies inside one frame (H * W % 256 == 0)
+                    atomicAdd(p.gn_stats + ((long long)frame * p.gn_C + n) * 2 + k, (double)sum);
+                }
+            }
+        }
     }
 }
 

@@ -38,6 +38,8 @@ struct Args {
     float* part;             //   partial sums part[((s * batch + b) * M + m) * N + n] instead of running the epilogue
                              // gemm8p: ksplit = workgroups of the main launch, part = scratch of the tail split (parked sums),
     int tail_ov;             //   tail_ov = the split's fixed cost in K-tile periods (gemm8p.hip: tail_plan)
+    double* gn_stats;        // conv kernels of gemm256.hip: [frame][gn_C][2] (sum, sum of squares) of the OUTPUT, accumulated in
+    int gn_C;                //   the epilogue for the GroupNorm that reads it (nullptr = none)
     ConvGeom cg; OutMap om;
 };
 

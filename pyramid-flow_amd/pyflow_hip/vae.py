@@ -117,7 +117,8 @@ class ConvW:
         self.N, self.n_valid, self.Cg, self.groups, self.cin_p = Np, n_valid, cg, groups, cp
 
 
-def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1, tdown=1, later_chunk=False):
+def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, down=1, tdown=1, later_chunk=False,
+         gn_stats=None):
     """dst[frames] = conv(src frames [0, Tc+2)) (+ res).  dst: PBuf (interior, slots from 2) or raw tuple.
     down = 2: spatially strided conv (CausalDownsample2x, modeling_resnet.py:291-336): output grid = src grid / 2.
     tdown = 2: CausalTemporalDownsample2x (:458-502).  First chunk / whole clip: windows start at the first cache slot
@@ -125,7 +126,10 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
     windows start at the second cache slot and an even chunk of Tc frames gives Tc / 2 outputs.
     Context-parallel mode (src.halo): the two cache slots come from the previous rank; output frames >= 2 do not read them
     and are launched while that exchange is in flight, frames 0-1 after it (CausalConv3d.context_parallel_forward,
-    modeling_causal_conv.py:95-114, without its blocking wait)."""
+    modeling_causal_conv.py:95-114, without its blocking wait).
+    gn_stats: zeroed double [>= Tc][dst.C][2] region for the GroupNorm that reads dst: where the conv kernel can, its
+    epilogue accumulates the statistics (pf_conv_desc.gn_stats) and dst.gn_ready = that region, so the norm skips its
+    statistics pass."""
     lib = L.load()
     slot_shift = 0
     T_in = Tc
@@ -175,9 +179,14 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
             assert (res.Hp, res.Wp, res.Cp) == (dst.Hp, dst.Wp, dst.Cp)
         d.out_scale = 1.0
         d.out_t_shift = ts_k
+        if gn_stats is not None:
+            d.gn_stats = gn_stats.data_ptr() + f0 * dst.C * 2 * 8
+            d.gn_C = dst.C
+            fused.append(bool(lib.pf_conv3d_fuses_gn_stats(C.byref(d))))
         ops.PROFILER.launch("conv3d", 2.0 * nf * (src.H // down) * (src.W // down) * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
                             lambda: check(lib.pf_conv3d_bf16(C.byref(d), stream())))
 
+    fused = []
     if cw.kt == 3 and src.halo is not None:
         if tdown == 1 and Tc > 2:
             h = src.exchange_halo_start()
@@ -192,6 +201,8 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
         launch(0, Tc)
     if dst is not None:
         dst.cur = Tc * st + t_shift
+        # statistics are complete only if EVERY launch of this conv accumulated them
+        dst.gn_ready = gn_stats if (gn_stats is not None and fused and all(fused)) else None
 
 
 class _TileProgram:
@@ -218,8 +229,9 @@ class _TileProgram:
                     self.tmax.append(tf_)
         # GroupNorm statistics: ONE arena with a region per norm layer, zeroed by one fill per chunk (the stats kernel
         # accumulates atomically) instead of one fill per layer
-        self.stats = torch.zeros(40 * max(self.tmax) * 512 * 2, dtype=torch.float64, device=self.dev)
+        self.stats = torch.zeros(100 * max(self.tmax) * 512 * 2, dtype=torch.float64, device=self.dev)
         self._stats_regions, self._stats_used = {}, 0
+        self.fuse_gn = getattr(vae, "fuse_gn_stats", True)     # conv epilogues accumulate the next norm's statistics
         self.pending = []           # (buffer, frames) cache-slot updates of the running chunk, flushed in one launch
         n = th * tw
         ca = vae.attn_pitch
@@ -266,6 +278,8 @@ class _TileProgram:
     def begin_chunk(self):
         self.stats[:max(self._stats_used, 1)].zero_() if self._stats_used else self.stats.zero_()
         del self.pending[:]
+        for b in self.bufs.values():
+            b.gn_ready = None       # statistics accumulated by a conv epilogue belong to the chunk that produced them
 
     def end_chunk(self):
         """flush the recorded cache-slot updates: one launch for every buffer of the program"""
@@ -293,10 +307,15 @@ class _TileProgram:
         st = self.stats[reg[0]:reg[0] + Tc * src.C * 2]
         lib = L.load()
         nbytes = 2.0 * Tc * src.H * src.W * src.C                       # one pass over the activation (bf16)
-        ops.PROFILER.launch("gn_stats", nbytes, lambda: check(lib.pf_gn_stats(
-            C.c_void_p(src.t.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int(Tc), C.c_int(src.C),
-            C.c_int(src.Cp), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Hp), C.c_int(src.Wp),
-            C.c_longlong(src.fs), C.c_longlong(src.off(2)), stream())))
+        ready = getattr(src, "gn_ready", None)
+        src.gn_ready = None
+        if ready is not None:        # the conv that wrote src accumulated (sum, sum of squares) in its epilogue
+            st = ready[:Tc * src.C * 2]
+        else:
+            ops.PROFILER.launch("gn_stats", nbytes, lambda: check(lib.pf_gn_stats(
+                C.c_void_p(src.t.data_ptr()), C.c_void_p(st.data_ptr()), C.c_int(Tc), C.c_int(src.C),
+                C.c_int(src.Cp), C.c_int(src.H), C.c_int(src.W), C.c_int(src.Hp), C.c_int(src.Wp),
+                C.c_longlong(src.fs), C.c_longlong(src.off(2)), stream())))
         if dst_raw is None:
             args = (dst.t.data_ptr(), dst.Cp, dst.Hp, dst.Wp, dst.fs, dst.off(2))
             dst.cur = Tc
@@ -311,14 +330,25 @@ class _TileProgram:
             C.c_int(args[2]), C.c_int(args[3]), C.c_longlong(args[4]), C.c_longlong(args[5]),
             C.c_float(1e-6), C.c_int(int(silu)), stream())))
 
+    def stats_region(self, key, channels):
+        """a zeroed-per-chunk region of the statistics arena for [tmax][channels][2] doubles"""
+        reg = self._stats_regions.get(key)
+        if reg is None:
+            size = max(self.tmax) * channels * 2
+            assert self._stats_used + size <= self.stats.numel(), "GroupNorm statistics arena too small"
+            reg = self._stats_regions[key] = (self._stats_used, size)
+            self._stats_used += size
+        return self.stats[reg[0]:reg[0] + reg[1]]
+
     def resnet(self, x, p, lvl, out_name, cout):
-        """CausalResnetBlock3D.forward (modeling_resnet.py:115-150)."""
+        """CausalResnetBlock3D.forward (modeling_resnet.py:115-150).  The statistics of norm2's input and of the block's
+        output (the next layer's norm input) are accumulated by the epilogues of conv1 / conv2 where the kernel can."""
         v = self.vae
         Tc = x.cur
         n1 = self.buf(p + "n1", lvl, x.H, x.W, x.C)
         self.gn(x, n1, p + "norm1")
         h = self.buf(p + "h", lvl, x.H, x.W, cout)
-        conv(n1, h, self.cw[p + "conv1"], Tc)
+        conv(n1, h, self.cw[p + "conv1"], Tc, gn_stats=self.stats_region(p + "conv1.out", cout) if self.fuse_gn else None)
         n1.shift_cache()
         self.release(n1)
         res = x
@@ -330,7 +360,8 @@ class _TileProgram:
         self.gn(h, n2, p + "norm2")
         self.release(h)
         out = self.buf(out_name, lvl, x.H, x.W, cout)
-        conv(n2, out, self.cw[p + "conv2"], Tc, res=res)
+        conv(n2, out, self.cw[p + "conv2"], Tc, res=res,
+             gn_stats=self.stats_region(p + "conv2.out", cout) if self.fuse_gn else None)
         n2.shift_cache()
         self.release(n2)
         self.release(res)                       # = x without a shortcut conv: the block's input is not read again
@@ -382,6 +413,7 @@ class _TileProgram:
             d.flags, d.out_scale, d.out_t_shift = GEMM_GATE_RES, 1.0, 0
             check(lib.pf_conv3d_bf16(C.byref(d), stream()))
         out.cur = Tc
+        out.gn_ready = None         # written outside conv(): no statistics came with it
         return out
 
     # ---- one chunk through post_quant_conv + decoder (modeling_enc_dec.py:302-366) -------------------

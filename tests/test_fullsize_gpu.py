@@ -128,10 +128,18 @@ def test_full_size_forward_invariants():
     finally:
         ops.gemm_set_policy(4)
     assert torch.equal(a, b)
-    assert rel_l2(a.cpu(), v1.cpu()) < 2e-3
+    # split vs whole tiles in all 24 blocks: two bf16 evaluations of the same forward (each 1e-2 from the fp32 oracle,
+    # tests/test_fulldepth_oracle_gpu.py) differ by rounding noise of that size, measured 9e-3
+    assert rel_l2(a.cpu(), v1.cpu()) < 2e-2
     del eng
     torch.cuda.empty_cache()
     sp = _full_engine(FluxEngineSP)
     sp.encode_context(enc)
     v4 = sp.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True).clone()
-    assert rel_l2(v4.cpu(), v1.cpu()) < 1e-3
+    assert rel_l2(v4.cpu(), v1.cpu()) < 2e-2          # other GEMM shapes (head-major columns, split MLP branch) -> other tail splits
+    ops.gemm_set_policy(-4)
+    try:
+        v5 = sp.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True).clone()
+    finally:
+        ops.gemm_set_policy(4)
+    assert rel_l2(v5.cpu(), a.cpu()) < 1e-3           # whole tiles only: the two layouts agree as they did before the split

@@ -100,3 +100,61 @@ def test_narrow_conv_every_channel_count_vs_conv3d(co):
     assert torch.isfinite(outs["narrow"]).all()                  # every one of the 8 pitch columns was written
     assert (outs["narrow"][..., co:] == 0).all()                 # ... the padding columns with zero filters and zero bias
     assert rel_l2(outs["narrow"][..., :co], outs["generic"][..., :co]) < 2e-3
+
+
+@pytest.mark.parametrize("co,with_res", [(128, False), (128, True), (256, True)])
+def test_conv_epilogue_accumulates_groupnorm_statistics(co, with_res):
+    """pf_conv_desc.gn_stats (round 3): the 256-row conv kernel leaves (sum, sum of squares) per output frame and channel of
+    what it STORED -- exactly what a pf_gn_stats pass over the output computes (up to the order of the fp32 / double sums);
+    the host then skips that pass (PBuf.gn_ready).  Plain conv and conv + shortcut add, N = 128 and 256 filters."""
+    from pyflow_hip import lib as L_
+    from pyflow_hip.lib import check, stream
+    from pyflow_hip.vae import PBuf, ConvW, conv
+    import ctypes as C
+    T, H, W, Ci = 4, 128, 128, 128           # 65 536 output pixels: the 256-row kernel's domain
+    g = torch.Generator().manual_seed(90 + co)
+    x = torch.randn(T, H, W, Ci, generator=g)
+    w = (torch.randn(co, Ci, 3, 3, 3, generator=g) * 0.05)
+    b = torch.randn(co, generator=g)
+    src = PBuf("x", T, H, W, Ci, "cuda")
+    src.t.view(T + 2, H + 2, W + 2, src.Cp)[2:, 1:-1, 1:-1, :Ci] = x.to("cuda", torch.bfloat16)
+    src.cur = T
+    res = None
+    if with_res:
+        res = PBuf("r", T, H, W, co, "cuda")
+        res.t.view(T + 2, H + 2, W + 2, res.Cp)[2:, 1:-1, 1:-1, :co] = torch.randn(T, H, W, co, generator=g).to("cuda", torch.bfloat16)
+        res.cur = T
+    dst = PBuf("y", T, H, W, co, "cuda")
+    stats = torch.zeros(T * co * 2, dtype=torch.float64, device="cuda")
+    conv(src, dst, ConvW(w, b, "cuda"), T, res=res, gn_stats=stats)
+    assert dst.gn_ready is stats                                       # the kernel that ran accumulates them
+    ref = torch.zeros(T * co * 2, dtype=torch.float64, device="cuda")
+    check(L_.load().pf_gn_stats(C.c_void_p(dst.t.data_ptr()), C.c_void_p(ref.data_ptr()), C.c_int(T), C.c_int(co),
+                                C.c_int(dst.Cp), C.c_int(H), C.c_int(W), C.c_int(dst.Hp), C.c_int(dst.Wp),
+                                C.c_longlong(dst.fs), C.c_longlong(dst.off(2)), stream()))
+    y = dst.t.view(T + 2, H + 2, W + 2, dst.Cp)[2:, 1:-1, 1:-1, :co].double()
+    exact = torch.stack([y.sum(dim=(1, 2)), (y * y).sum(dim=(1, 2))], dim=-1).reshape(-1)      # [T][co][2]
+    assert exact.abs().max() > 0
+    scale = exact.view(T, co, 2)[..., 1].sqrt().max().item() * (H * W) ** 0.5
+    assert (ref - exact).abs().max() <= 1e-4 * max(scale, 1.0)         # the separate pass (fp32 partial sums)
+    assert (stats - exact).abs().max() <= 1e-4 * max(scale, 1.0)       # the epilogue's sums
+    # a shape the epilogue cannot serve (frames of 48 x 40 = 1 920 pixels: not a multiple of 256) falls back silently
+    src2 = PBuf("x2", T, 48, 40, Ci, "cuda")
+    src2.cur = T
+    dst2 = PBuf("y2", T, 48, 40, co, "cuda")
+    conv(src2, dst2, ConvW(w, b, "cuda"), T, gn_stats=stats)
+    assert dst2.gn_ready is None
+
+
+def test_decode_same_with_and_without_fused_groupnorm_statistics():
+    from pyflow_hip import synth
+    from pyflow_hip.vae import CausalVideoVAE
+    cfg = synth.TINY_VAE
+    sd = _sd(cfg)
+    z = torch.randn(1, 16, 3, 32, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    outs = []
+    for fuse in (True, False):
+        vae = CausalVideoVAE(sd, cfg, "cuda")
+        vae.fuse_gn_stats = fuse
+        outs.append(vae.decode(z, temporal_chunk=True, window_size=1).sample.float().cpu())
+    assert rel_l2(outs[0], outs[1]) < 2e-3 and outs[0].abs().max() > 0
