@@ -428,7 +428,7 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
         return 0;
     }
     const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
-    hipFuncSetAttribute((const void*)gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    PF_SET_MAX_LDS_ONCE((gemm_kernel<true>), SMEM_BYTES);
     hipLaunchKernelGGL(gemm_kernel<true>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(hipGetErrorString(e));

@@ -476,12 +476,12 @@ class FluxEngine(DeviceModuleAPI):
             ln(L_img, Lt * d, mb + 0, mb + d)
             if tail:
                 ops.gemm(xn, blk["kvq_img"][0], big, L_img, 2 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, tail_workspace=ws_img)
                 ops.gemm(xn, blk["kvq_img"][0], big, n_act, d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=r0 * d, c_off=r0 * 3 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d, workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=r0 * d, c_off=r0 * 3 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d, tail_workspace=ws_img)
             else:
                 ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, tail_workspace=ws_img)
             join(1, 0)
             ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
                              blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
@@ -502,13 +502,13 @@ class FluxEngine(DeviceModuleAPI):
                              gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base, workspace=ws_txt)
             ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
-                     flags=GEMM_GATE_RES, a_off=r0 * 3 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, workspace=ws_img)
+                     flags=GEMM_GATE_RES, a_off=r0 * 3 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, tail_workspace=ws_img)
             ln(n_act, r0 * d, mb + 3 * d, mb + 4 * d)
             ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
-                     strideA=Ld, strideC=L4, gelu_from=0, a_off=r0 * d, c_off=mlp_base + r0 * 4 * d, workspace=ws_img)
+                     strideA=Ld, strideC=L4, gelu_from=0, a_off=r0 * d, c_off=mlp_base + r0 * 4 * d, tail_workspace=ws_img)
             ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                      res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
-                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + r0 * 4 * d, c_off=r0 * d, r_off=r0 * d, workspace=ws_img)
+                     gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + r0 * 4 * d, c_off=r0 * d, r_off=r0 * d, tail_workspace=ws_img)
             if debug is not None and ("hidden_d0" not in debug or "blocks" in debug):
                 join(1, 0)
                 snap = hidden[:B * L * d].view(B, L, d).clone()
@@ -527,9 +527,9 @@ class FluxEngine(DeviceModuleAPI):
                 # the attention rows and proj_out only for the last n_cur rows -- identical values, less work.
                 r0 = L - n_cur
                 ops.gemm(xn, blk["kvqm"][0], big, L, 2 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, workspace=ws_img)
+                         strideC=L7, tail_workspace=ws_img)
                 ops.gemm(xn, blk["kvqm"][0], big, n_cur, 5 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, gelu_from=d, a_off=r0 * d, c_off=r0 * 7 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d, workspace=ws_img)
+                         strideC=L7, gelu_from=d, a_off=r0 * d, c_off=r0 * 7 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d, tail_workspace=ws_img)
                 ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H,
                                  q_scale=qs, eps=w.qk_eps)
                 ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
@@ -537,16 +537,16 @@ class FluxEngine(DeviceModuleAPI):
                               q_row_begin=r0)
                 ops.gemm(big, blk["out"][0], hidden, n_cur, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
-                         flags=GEMM_GATE_RES, a_off=r0 * 7 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, workspace=ws_img)
+                         flags=GEMM_GATE_RES, a_off=r0 * 7 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, tail_workspace=ws_img)
                 continue
             ops.gemm(xn, blk["kvqm"][0], big, L, 7 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                     strideC=L7, gelu_from=3 * d, workspace=ws_img)
+                     strideC=L7, gelu_from=3 * d, tail_workspace=ws_img)
             ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H, q_scale=qs)
             ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
             ops.gemm(big, blk["out"][0], hidden, L, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
-                     flags=GEMM_GATE_RES, a_off=2 * d, workspace=ws_img)
+                     flags=GEMM_GATE_RES, a_off=2 * d, tail_workspace=ws_img)
             if debug is not None and "blocks" in debug:
                 debug["blocks"].append(hidden[:B * L * d].view(B, L, d).clone())
         if debug is not None:

@@ -104,7 +104,7 @@ def _launch(world, script, args, tmp_path):
                 q.kill()
             raise
         logs.append(o.decode()[-2000:])
-    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+    assert all(p.returncode == 0 for p in procs), f"return codes {[p.returncode for p in procs]}\n" + "\n----\n".join(logs)
     print(out.read_text())
 
 
