@@ -378,32 +378,9 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     return 0;
 }
 
-// GroupNorm statistics in the conv epilogue: only the 256-row ping-pong kernel at BN = 128 / 256 accumulates them, for a
-// plain output map (no pixel shuffle / depth-to-time / frame drop) whose frames are whole numbers of 256-pixel tiles
-static bool conv_fuses_gn_stats(const pf_conv_desc* d) {
-    if (!d->gn_stats || d->gn_C <= 0) return false;
-    if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->out_t_shift != 0 || (d->flags & PF_GEMM_OUT_F32)) return false;
-    if (((long long)d->H * d->W_) % 256 != 0) return false;
-    const int ntaps = d->kt * d->kh * d->kw;
-    const long long M = (long long)d->T * d->H * d->W_;
-    const int nv = d->n_valid > 0 ? d->n_valid : d->N;
-    if (nv > d->gn_C || M > 0x7fffffff) return false;
-    if (g_narrow_enabled && pf_conv_narrow_supports(d)) return false;
-    if (use_gemm8p((int)M, 1, d->N, ntaps * d->Cin) && nv % 8 == 0 && !(d->flags & PF_GEMM_GATE_RES)) return false;   // gemm8p conv
-    const int bn = pf_gemm256_pick(M, (int)M, 1, d->N, gemm256_force());
-    return bn == 128 || bn == 256;
-}
-extern "C" int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d) { return d && conv_fuses_gn_stats(d) ? 1 : 0; }
-
-extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
-    if (!d || !d->X || !d->W || !d->Y) return set_err("pf_conv3d_bf16: null operand");
-    const int ntaps = d->kt * d->kh * d->kw;
-    const int K = ntaps * d->Cin;
-    if (d->Cin % BK != 0) return set_err("pf_conv3d_bf16: Cin must be a multiple of 64 (pad channels)");
-    if (d->N % BN != 0) return set_err("pf_conv3d_bf16: N must be a multiple of 128 (pad filters)");
-    if (d->T <= 0 || d->H <= 0 || d->W_ <= 0) return set_err("pf_conv3d_bf16: empty problem");
-    if (g_narrow_enabled && pf_conv_narrow_supports(d)) return pf_conv_narrow_launch(d, stream);
-    Args a{};
+// ---- CausalConv3d: one routing decision shared by the launch and by pf_conv3d_fuses_gn_stats
+static void conv_args(const pf_conv_desc* d, Args& a) {
+    const int K = d->kt * d->kh * d->kw * d->Cin;
     a.A = (const bf16_t*)d->X; a.W = (const bf16_t*)d->W; a.C = d->Y;
     a.bias = d->bias; a.res = (const bf16_t*)d->res; a.gate = nullptr;
     a.M = d->T * d->H * d->W_; a.N = d->N; a.K = K; a.lda = 0; a.ldw = K; a.ldc = d->N; a.ldr = d->N;
@@ -413,23 +390,53 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     a.cg = ConvGeom{d->H, d->W_, d->Hp, d->Wp, d->Cin, d->kt, d->kh, d->kw, d->in_base_off,
                     d->in_sh > 0 ? d->in_sh : 1, d->in_sw > 0 ? d->in_sw : 1, d->in_st > 0 ? d->in_st : 1};
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
+}
+// -1 = conv_narrow_kernel, 8 = gemm8p_kernel<true, 0>, 128 / 192 / 256 = gemm256_kernel<BN, true>, 0 = gemm_kernel<true>
+static int conv_route(const pf_conv_desc* d, const Args& a) {
+    if (g_narrow_enabled && pf_conv_narrow_supports(d)) return -1;
+    if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) return 8;
+    return pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force());
+}
+// GroupNorm statistics in the conv epilogue: only the 256-row ping-pong kernel at BN = 128 / 256 accumulates them, for a
+// plain output map (no pixel shuffle / depth-to-time / frame drop) whose frames are whole numbers of 256-pixel tiles
+static bool conv_fuses_gn_stats(const pf_conv_desc* d, const Args& a, int route) {
+    if (!d->gn_stats || d->gn_C <= 0 || a.n_valid > d->gn_C) return false;
+    if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->out_t_shift != 0 || (d->flags & PF_GEMM_OUT_F32)) return false;
+    if (((long long)d->H * d->W_) % 256 != 0) return false;
+    return route == 128 || route == 256;
+}
+static const char* conv_check(const pf_conv_desc* d) {
+    if (!d || !d->X || !d->W || !d->Y) return "pf_conv3d_bf16: null operand";
+    if (d->Cin % BK != 0) return "pf_conv3d_bf16: Cin must be a multiple of 64 (pad channels)";
+    if (d->N % BN != 0) return "pf_conv3d_bf16: N must be a multiple of 128 (pad filters)";
+    if (d->T <= 0 || d->H <= 0 || d->W_ <= 0) return "pf_conv3d_bf16: empty problem";
+    if ((long long)d->T * d->H * d->W_ > 0x7fffffffll) return "pf_conv3d_bf16: more than 2^31 output pixels";
+    return nullptr;
+}
+extern "C" int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d) {
+    if (conv_check(d)) return 0;
+    Args a{};
+    conv_args(d, a);
+    return conv_fuses_gn_stats(d, a, conv_route(d, a)) ? 1 : 0;
+}
+
+extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
+    if (const char* msg = conv_check(d)) return set_err(msg);
+    Args a{};
+    conv_args(d, a);
+    const int route = conv_route(d, a);
+    if (route == -1) return pf_conv_narrow_launch(d, stream);
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
-    if (conv_fuses_gn_stats(d)) { a.gn_stats = d->gn_stats; a.gn_C = d->gn_C; }
-    if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) {
+    if (conv_fuses_gn_stats(d, a, route)) { a.gn_stats = d->gn_stats; a.gn_C = d->gn_C; }
+    if (route == 8) {
         pf_gemm8p_launch(a, true, stream, nullptr, 0);
-        hipError_t e2 = hipGetLastError();
-        if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
-        return 0;
+    } else if (route > 0) {
+        pf_gemm256_launch(a, route, true, stream);
+    } else {
+        const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
+        PF_SET_MAX_LDS_ONCE((gemm_kernel<true>), SMEM_BYTES);
+        hipLaunchKernelGGL(gemm_kernel<true>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
     }
-    if (const int bn = pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force())) {
-        pf_gemm256_launch(a, bn, true, stream);
-        hipError_t e2 = hipGetLastError();
-        if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
-        return 0;
-    }
-    const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
-    PF_SET_MAX_LDS_ONCE((gemm_kernel<true>), SMEM_BYTES);
-    hipLaunchKernelGGL(gemm_kernel<true>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(hipGetErrorString(e));
     return 0;
