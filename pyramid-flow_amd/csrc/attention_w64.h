@@ -35,6 +35,10 @@ template <int OCC, int MODE = 0, int NW = 4>
 __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     constexpr int ABL = MODE;
     constexpr bool FAST = (MODE & 1) != 0, FIXUP = (MODE & 4) != 0;
+    // bit 3 (lab only, not instantiated by the library; written at the end of round 3, not yet measured): row sums of the
+    // bf16-ROUNDED P by v_dot2c_f32_bf16 against (1, 1) -- 4 instead of 8 vector instructions per slot, and the
+    // denominator then sums exactly the values the PV MFMAs multiply
+    constexpr bool DOTSUM = (MODE & 8) != 0;
     constexpr int PJ = 8 / NW;                 // DMA pieces per wave of each of the K and V^T tiles (8 pieces of 8 rows each)
     constexpr int NT = NW / 2;                 // 128-row query tiles (the granularity of tile_kv_end / q_row_begin) per workgroup
     if (FIXUP) {
@@ -229,8 +233,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + e]);
-            ps += v;
+            if (!DOTSUM) ps += v;
             pf[g][e] = (bf16_t)v;
+        }
+        if (DOTSUM) {
+            const bf16x2_t ones = {(bf16_t)1.0f, (bf16_t)1.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x2_t pr = {pf[g][2 * q], pf[g][2 * q + 1]};
+                ps = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, ps, false);
+            }
         }
         // pinned HERE: the fragment is only consumed by a later segment, and LLVM otherwise sinks the whole slot down to its
         // use (across the branches between the segments), which puts all exponentials behind the MFMAs they should run under
