@@ -455,6 +455,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
     CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
     const int grid128 = ((pl.nqt + 3) / 4) * H * B;
@@ -476,6 +477,9 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((attn64_kernel<2, 4, 8>), dim3(grid128), dim3(512), SM128, st, a); }, true});
     vars.push_back({"attn64 FAST alone", [&] { hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     // written at the end of round 3, first measured in round 4: row sums by v_dot2c_f32_bf16 on the packed P (MODE bit 3)
+    vars.push_back({"attn64 FAST, v_pk_add_f32 row sums + FIXUP launch", [&] {
+        hipLaunchKernelGGL((attn64_kernel<2, 17>), dim3(grid64), dim3(256), SM64, st, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 FAST, dot2 row sums + FIXUP launch", [&] {
         hipLaunchKernelGGL((attn64_kernel<2, 9>), dim3(grid64), dim3(256), SM64, st, a);
         hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});

@@ -15,6 +15,7 @@
 // because the contraction-slot -> key permutation of the C layout is mirrored in the V^T image
 // (pf_v_transpose writes keys permuted within groups of 16).  K and V^T tiles arrive by LDS-DMA
 // with source-side XOR swizzle, double-buffered, one barrier per KV tile.
+#include <type_traits>
 #include "common.h"
 #include "pyflow_hip.h"
 

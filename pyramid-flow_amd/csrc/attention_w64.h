@@ -39,6 +39,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     // bf16-ROUNDED P by v_dot2c_f32_bf16 against (1, 1) -- 4 instead of 8 vector instructions per slot, and the
     // denominator then sums exactly the values the PV MFMAs multiply
     constexpr bool DOTSUM = (MODE & 8) != 0;
+    // bit 4 (lab only, likewise): the fp32 row sums as TWO partial sums per block added by v_pk_add_f32 (32 instead of 64 adds)
+    constexpr bool PKSUM = (MODE & 16) != 0;
+    typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
+    using ps_t = typename std::conditional<PKSUM, f32x2_t_, float>::type;
+    auto ps_zero = [] { if constexpr (PKSUM) return (f32x2_t_){0.f, 0.f}; else return 0.f; };
+    auto ps_total = [](const ps_t& v) { if constexpr (PKSUM) return v[0] + v[1]; else return v; };
     constexpr int PJ = 8 / NW;                 // DMA pieces per wave of each of the K and V^T tiles (8 pieces of 8 rows each)
     constexpr int NT = NW / 2;                 // 128-row query tiles (the granularity of tile_kv_end / q_row_begin) per workgroup
     if (FIXUP) {
@@ -229,14 +235,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         }
     };
     // exponentials + partial row sum + bf16 P fragment of contraction slot g (keys 16 g .. 16 g + 15 in C-layout order)
-    auto exp_slot = [&](int g, f32x16_t* s, float& ps, bf16x8_t* pf) {
+    auto exp_slot = [&](int g, f32x16_t* s, ps_t& ps, bf16x8_t* pf) {
+        [[maybe_unused]] float pv_even = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float v = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + e]);
-            if (!DOTSUM) ps += v;
+            if constexpr (PKSUM) {
+                if (e & 1) ps += (f32x2_t_){pv_even, v};
+                else pv_even = v;
+            } else if constexpr (!DOTSUM) {
+                ps += v;
+            }
             pf[g][e] = (bf16_t)v;
         }
-        if (DOTSUM) {
+        if constexpr (DOTSUM && !PKSUM) {
             const bf16x2_t ones = {(bf16_t)1.0f, (bf16_t)1.0f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -289,14 +301,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         const bool active = jt < my_nt;
         f32x16_t sb[2];
         bf16x8_t pb[4];
-        float psb = 0.f;
+        ps_t psb = ps_zero();
         if (active && FAST) {
             // FAST: no maximum, no shift.  The exponentials of a block run under the OTHER block's MFMAs:
             //   QK(A) | QK(B) + exp(A) slots 0-2 | PV(A) + exp(A) slot 3, exp(B) slots 0-1 | boundary | PV(B) + exp(B) slots 2-3 + DMA
             f32x16_t sa[2];
             bf16x8_t pa[4];
             const f32x16_t zero = bcast(0.f);
-            float psa = 0.f;
+            ps_t psa = ps_zero();
             qk_slice(0, qfa, zero, sa);
             PF_SEG();
             read_q(1, qfb);
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
             exp_slot(1, sb, psb, pb);
             PF_SEG();
             pv_slot(0, 3, pa);
-            l[0] += psa;
+            l[0] += ps_total(psa);
             PF_SEG();
             stamp(2);
         }
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
             PF_SEG();
             stamp(1);
             // S2: exponentials of block A one contraction slot ahead of its PV MFMAs; the maximum of block B at the end
-            float psa = 0.f;
+            ps_t psa = ps_zero();
             exp_slot(0, sa, psa, pa);
             PF_SEG();
 #pragma unroll
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
                 exp_slot(g + 1, sa, psa, pa);
                 PF_SEG();
             }
-            l[0] += psa;
+            l[0] += ps_total(psa);
             pv_slot(0, 3, pa);
             stamp(2);
             if (MASKED) apply_mask(1, sb, j0);
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
                 }
                 PF_SEG();
             }
-            l[1] += psb;
+            l[1] += ps_total(psb);
             stamp(6);
             if (ABL & 2) ph[7] += 1;
         } else if (active) {
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
                 }
                 PF_SEG();
             }
-            l[1] += psb;
+            l[1] += ps_total(psb);
             stamp(6);
             if (ABL & 2) ph[7] += 1;
         } else if (more) {
