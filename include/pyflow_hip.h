@@ -25,6 +25,10 @@ extern "C" {
 typedef struct ihipStream_t* pf_stream_t; /* == hipStream_t */
 
 const char* pf_last_error(void);
+/* ABI version of THIS header.  pf_version() returns the version the library was built with; a caller compares the two
+ * before its first launch (a descriptor struct that grew -- 2 -> 3: pf_attn_desc.workspace / workspace_bytes,
+ * pf_conv_desc.gn_stats / gn_C -- would otherwise be read past its end). */
+#define PF_ABI_VERSION 3
 int pf_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: 0 pf_gemm_desc, 1 pf_conv_desc, 2 pf_attn_desc,
  * 3 pf_attn_small_desc (-1 otherwise) -- lets a foreign-language binding (ctypes / cgo / JNI struct mirrors) verify its

@@ -456,6 +456,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
     CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
     const int grid128 = ((pl.nqt + 3) / 4) * H * B;
@@ -482,6 +483,10 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 FAST, dot2 row sums + FIXUP launch", [&] {
         hipLaunchKernelGGL((attn64_kernel<2, 9>), dim3(grid64), dim3(256), SM64, st, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});
+    // round 4: row sums from the matrix pipe (one 16x16x32 MFMA of P against a constant 0/1 operand per 16-key slot)
+    vars.push_back({"attn64 FAST, MFMA row sums + FIXUP launch", [&] {
+        hipLaunchKernelGGL((attn64_kernel<2, 33>), dim3(grid64), dim3(256), SM64, st, a);
         hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), SM64, st, a); }, false});

@@ -92,10 +92,20 @@ def build_mask(enc_mask, frame_t_img):
     return m
 
 
+HEAD_CHUNK_ABOVE_L = 8192      # longer sequences run the (per-head independent) SDPA a few heads at a time: bounded memory
+HEAD_CHUNK = 5
+
+
 def attention(q, k, v, mask):
-    # blk:361-365 ; q,k,v [B,L,H,hd]
-    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
-                                       attn_mask=mask)
+    # blk:361-365 ; q,k,v [B,L,H,hd].  Heads are independent in SDPA, so evaluating them in groups is the same arithmetic
+    # per head (tests/test_oracle_vs_reference.py pins the grouped form to the one-call form); it only bounds the memory
+    # of a fallback that materialises [B, H, L, L] scores at the headline sequence length (L = 15 488: 57 GB in one call)
+    qt, kt, vt = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+    if q.shape[1] <= HEAD_CHUNK_ABOVE_L:
+        o = F.scaled_dot_product_attention(qt, kt, vt, attn_mask=mask)
+    else:
+        o = torch.cat([F.scaled_dot_product_attention(qt[:, h:h + HEAD_CHUNK], kt[:, h:h + HEAD_CHUNK], vt[:, h:h + HEAD_CHUNK],
+                                                      attn_mask=mask) for h in range(0, qt.shape[1], HEAD_CHUNK)], dim=1)
     return o.transpose(1, 2).flatten(2, 3)
 
 

@@ -346,8 +346,22 @@ extern "C" long long pf_attention_workspace_bytes(int B, int H, int L) {
 
 // the 64-rows-per-wave pair needs caller scratch, pre-scaled q, 16-byte aligned output rows and at least two 256-row
 // workgroups per CU (below that the 128-row kernel keeps more of the chip busy)
+// ... and an output that either does not touch Q at all or IS Q (the in-place form of the DiT: same address, leading
+// dimension, batch stride and packed heads -- then every wave overwrites exactly the 64 Q rows it alone reads, and the
+// fast pass leaves the rows of a flagged wave unwritten for the fix-up launch; attention_w64.h).  Any other overlap of
+// the two ranges would let the fix-up launch re-read overwritten Q: those problems stay with the 128-row kernel.
+static bool o_aliases_q_safely(const pf_attn_desc* d) {
+    const int hs = d->head_stride_qk > 0 ? d->head_stride_qk : HD;
+    const long long q_ext = ((long long)(d->B - 1) * d->strideQ + (long long)(d->L - 1) * d->ldq + (long long)(d->H - 1) * hs + HD) * 2;
+    const long long o_ext = ((long long)(d->B - 1) * d->strideO + (long long)(d->L - 1) * d->ldo + (long long)d->H * HD) * 2;
+    const uintptr_t q = (uintptr_t)d->Q, o = (uintptr_t)d->O;
+    if (o + o_ext <= q || q + q_ext <= o) return true;                    // disjoint
+    return o == q && d->ldo == d->ldq && d->strideO == d->strideQ && hs == HD;
+}
+
 static bool use_w64(const pf_attn_desc* d) {
     if (!d->q_prescaled || !d->workspace || d->L <= 0) return false;
+    if (!o_aliases_q_safely(d)) return false;
     const int nqt = (d->L + QB - 1) / QB;
     const int qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
     const long long grid64 = (long long)((nqt + 1) / 2 - qt0 / 2) * d->H * d->B;

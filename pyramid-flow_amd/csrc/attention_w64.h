@@ -41,18 +41,32 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     constexpr bool DOTSUM = (MODE & 8) != 0;
     // bit 4 (lab only, likewise): the fp32 row sums as TWO partial sums per block added by v_pk_add_f32 (32 instead of 64 adds)
     constexpr bool PKSUM = (MODE & 16) != 0;
+    // bit 5 MMSUM (FAST only): the row sums come from the MATRIX pipe.  The bf16 P fragment of a 16-key slot (the B operand of
+    //       the PV MFMAs: lane l holds P[key 8 (l / 32) + j][row l % 32]) is fed once more to v_mfma_f32_16x16x32_bf16, which
+    //       reads the same registers as B'[k' = 8 (l / 16) + j][n' = l % 16]; against the constant A[m][k'] = [(k' / 8) % 2 == m % 2]
+    //       it returns D[m][n'] = the slot's sum of row n' (m even) or row n' + 16 (m odd) over BOTH key halves.  One 16-cycle
+    //       MFMA per slot (+12.5 % matrix-pipe time) replaces 16 v_add_f32 per slot and lane (64 of ~160 vector instructions
+    //       per 32 rows x 64 keys of a kernel that is bound by vector issue); the sums accumulate in 4 registers per block and
+    //       are read out once, in the epilogue; the denominator then sums exactly the rounded values the numerator multiplies.
+    constexpr bool MMSUM = (MODE & 32) != 0;
+    static_assert(!MMSUM || (FAST && !DOTSUM && !PKSUM), "MMSUM is a form of the FAST pass");
     typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
     using ps_t = typename std::conditional<PKSUM, f32x2_t_, float>::type;
     auto ps_zero = [] { if constexpr (PKSUM) return (f32x2_t_){0.f, 0.f}; else return 0.f; };
     auto ps_total = [](const ps_t& v) { if constexpr (PKSUM) return v[0] + v[1]; else return v; };
     constexpr int PJ = 8 / NW;                 // DMA pieces per wave of each of the K and V^T tiles (8 pieces of 8 rows each)
     constexpr int NT = NW / 2;                 // 128-row query tiles (the granularity of tile_kv_end / q_row_begin) per workgroup
+    // FIXUP: only the waves the fast pass flagged recompute and store.  The pair is ALIAS-SAFE for the in-place form the DiT
+    // uses (O == Q: same rows, same columns): a wave reads only its own 64 Q rows and writes only its own 64 O rows, the
+    // fast pass does not store the rows of a wave it flags, so the Q rows a fix-up wave re-reads are still the caller's.
+    bool mine = true;
     if (FIXUP) {
         const int* f = p.wgflags + NW * blockIdx.x;
         int any = 0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) any |= f[i];
         if (any == 0) return;
+        mine = f[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)] != 0;
     }
     constexpr int QB2 = 64 * NW, QWAVE = 64 * HD * 2;             // 8 KiB of Q per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * ABUF (K | V^T tile ring) + NW * QWAVE (Q rows)
@@ -101,7 +115,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     const int wmax_s = __builtin_amdgcn_readfirstlane(wmax), wmin_s = __builtin_amdgcn_readfirstlane(wmin);
     // tiles this wave computes: the text tiles and every image tile below the largest visibility bound of its 64 rows
     // (bounds are monotone in the key index, so the active tiles are a prefix; the rest only keeps the barrier / DMA going)
-    const int my_nt = min(ntiles, (max(p.Lt, wmax_s) + KB - 1) / KB);
+    // rows below the caller's q_row_begin (p.qt0 counts 128-row tiles; a 256-row workgroup may start 128 rows earlier) are
+    // neither computed, flagged nor stored; in the fix-up launch the same holds for the waves the fast pass did not flag
+    const int row_lo = p.qt0 * QB;
+    const bool wave_runs = mine && (q0 + wid * 64 + 64 > row_lo);
+    const int my_nt = wave_runs ? min(ntiles, (max(p.Lt, wmax_s) + KB - 1) / KB) : 0;
 
     // ---- DMA sources: wave owns pieces i = wid*2 + j (rows 8i..8i+7) of the K and V^T tiles.  Addresses are a wave-uniform
     //      tile base (scalar registers, advanced per tile) + one constant 32-bit byte offset per lane and piece
@@ -146,6 +164,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[x][i][r] = 0.f;
     float m[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+    f32x4_t lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // MMSUM: row sums as a 16 x 16 MFMA accumulator per block
+    bf16x8_t ones_a;                                                      // MMSUM: the constant A operand (see above)
+    {
+        const bf16_t one_or_zero = (((lane >> 4) ^ lane) & 1) == 0 ? (bf16_t)1.0f : (bf16_t)0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones_a[e] = one_or_zero;
+    }
     bool fresh[2] = {true, true};        // the row has not seen a key yet (its reference is still unset)
     const float NINF = -__builtin_inff();
 
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
             if constexpr (PKSUM) {
                 if (e & 1) ps += (f32x2_t_){pv_even, v};
                 else pv_even = v;
-            } else if constexpr (!DOTSUM) {
+            } else if constexpr (!DOTSUM && !MMSUM) {
                 ps += v;
             }
             pf[g][e] = (bf16_t)v;
@@ -263,6 +288,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     auto pv_slot = [&](int x, int g, const bf16x8_t* pf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) o[x][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i][g], pf[g], o[x][i], 0, 0, 0);
+        if constexpr (MMSUM) lacc[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_a, pf[g], lacc[x], 0, 0, 0);
+    };
+    // a block's denominator at the end: the VALU partial sums of the two key halves, or the MFMA accumulator's entry for
+    // this lane's row (register 0: rows 0..15 of the block, register 1: rows 16..31; both key halves already inside)
+    auto row_sum = [&](int x) {
+        if constexpr (MMSUM) return (lane & 16) ? lacc[x][1] : lacc[x][0];
+        else { float lx = l[x]; lx += __shfl_xor(lx, 32); return lx; }
     };
 
     // ---- prologue: Q rows and tiles 0, 1 in flight; tile 0 and Q landed; first K / Q fragments requested
@@ -480,28 +512,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
 
     // ---- FAST: did every valid row end with a usable denominator?  (inf / NaN: a score beyond the fp32 range of exp2; ~0: every
     //      score far below zero.)  One flag per wave; the FIXUP launch recomputes flagged workgroups with the running maximum.
+    bool store = wave_runs;
     if (FAST) {
         bool bad = false;
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            float lx = l[x];
-            lx += __shfl_xor(lx, 32);
-            const bool valid = q0 + wid * 64 + x * 32 + frow < p.L;
+            const float lx = row_sum(x);
+            const int qrow = q0 + wid * 64 + x * 32 + frow;
+            const bool valid = qrow < p.L && qrow >= row_lo;
             bad = bad || (valid && !(lx > 1e-30f && lx < 1e30f));
         }
-        const int any_bad = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+        const int any_bad = (wave_runs && __builtin_amdgcn_ballot_w64(bad) != 0) ? 1 : 0;
         if (lane == 0) p.wgflags[NW * blockIdx.x + wid] = any_bad;
+        store = store && !any_bad;          // a flagged wave leaves its rows (== its Q rows when O aliases Q) to the fix-up launch
     }
+    if (!store) return;
 
     // ---- epilogue: O = o / l, bf16, 16-byte stores (a lane pair (l, l^32) holds 8 consecutive features of a row after
     //      one half-exchange per register pair)
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-        float lx = l[x];
-        lx += __shfl_xor(lx, 32);
+        const float lx = row_sum(x);
         const float inv = lx > 0.f ? 1.0f / lx : 0.f;
         const int qrow = q0 + wid * 64 + x * 32 + frow;
-        const bool qvalid = qrow < p.L;
+        const bool qvalid = qrow < p.L && qrow >= row_lo;
         bf16_t* op = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + h * HD + 8 * hi;
 #pragma unroll
         for (int i = 0; i < 2; ++i)

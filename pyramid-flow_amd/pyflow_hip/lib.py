@@ -59,6 +59,7 @@ class AttnSmallDesc(C.Structure):
                 ("bias", C.c_void_p), ("key_mask", C.c_void_p), ("causal", C.c_int), ("scale", C.c_float)]
 
 
+ABI_VERSION = 3          # PF_ABI_VERSION of include/pyflow_hip.h
 GEMM_GATE_RES = 1
 GEMM_OUT_F32 = 2
 GEMM_ACT_QUICK_GELU = 4
@@ -99,6 +100,8 @@ def load():
     lib.pf_cmdlist_create.restype = C.c_void_p
     lib.pf_attention_workspace_bytes.restype = C.c_longlong
     lib.pf_gemm_workspace_bytes.restype = C.c_longlong
+    if lib.pf_version() != ABI_VERSION:
+        raise RuntimeError(f"pyflow_hip: {LIB_PATH} has ABI version {lib.pf_version()}, this host expects {ABI_VERSION}: rebuild it")
     for which, cls in enumerate((GemmDesc, ConvDesc, AttnDesc, AttnSmallDesc)):       # struct mirrors vs the compiled layout
         if lib.pf_struct_size(C.c_int(which)) != C.sizeof(cls):
             raise RuntimeError(f"pyflow_hip: {cls.__name__} is {C.sizeof(cls)} bytes here but "

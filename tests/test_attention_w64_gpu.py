@@ -142,3 +142,64 @@ def test_fix_up_pass_recomputes_rows_outside_the_fast_window(case):
     err = rel_l2(out.float().cpu(), ref.cpu())
     print(f"{case}: attention pair vs dense fp32 reference rel-L2 {err:.3e}")
     assert err < 1e-2
+
+
+@pytest.mark.parametrize("case", ["benign", "overflow", "underflow", "mixed"])
+def test_pair_in_place_output_over_q(case):
+    """the DiT's call form (flux.py): O aliases Q -- same address, leading dimension and batch stride.  The fast pass must
+    not store the rows of a wave it flags, so that the fix-up launch still reads the caller's Q there (the round-3 pair
+    overwrote them and recomputed from garbage); result == the out-of-place run bit for bit."""
+    from pyflow_hip import ops
+    from pyflow_hip.plan import SequencePlan
+    B = 2
+    plan = SequencePlan(CLIPS, _mask(), [16, 24, 24], DEV)
+    L, Lp = plan.L, plan.Lp
+    g = torch.Generator(device=DEV).manual_seed(7)
+    qkv = torch.randn(B, L, 3 * D, generator=g, device=DEV)
+    qkv[..., 2 * D:] *= 0.125 * ops.LOG2E
+    q = qkv[..., 2 * D:]
+    k = qkv[..., :D]
+    if case in ("overflow", "mixed"):
+        q[:, 700:900] += 2.0
+        k[:, 1000:1040] += 3.0
+    if case in ("underflow", "mixed"):
+        q[:, 2000:2200] -= 3.0
+        k += 1.3
+    qkv = qkv.to(torch.bfloat16)
+    ref = _reference(qkv, plan, B, L)
+    out = _run(qkv, plan, B, L, Lp)                      # separate output
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 1e-2
+    vT = torch.zeros(B, H, 64, Lp, dtype=torch.bfloat16, device=DEV)
+    ops.v_transpose(qkv, vT, D, 3 * D, L * 3 * D, B, H, L, Lp)
+    buf = qkv.clone()
+    kv_before = buf[..., :2 * D].clone()
+    ops.attention(buf, buf, vT, buf, 2 * D, 0, 2 * D, 3 * D, L * 3 * D, B, H, L, Lp, LT, plan, 0.125, q_prescaled=True)
+    assert torch.equal(buf[..., :2 * D], kv_before)      # K | V columns untouched
+    inplace = buf[..., 2 * D:]
+    assert torch.isfinite(inplace.float()).all()
+    assert torch.equal(inplace, out), f"{case}: in-place differs from out-of-place, rel {rel_l2(inplace.float().cpu(), out.float().cpu()):.3e}"
+
+
+def test_pair_is_not_chosen_for_a_partial_overlap_of_output_and_q():
+    """O inside Q's address range but not the in-place form (other leading dimension): stays with the 128-row kernel"""
+    from pyflow_hip import lib, ops
+    from pyflow_hip.plan import SequencePlan
+    B = 2
+    plan = SequencePlan(CLIPS, _mask(), [16, 24, 24], DEV)
+    L, Lp = plan.L, plan.Lp
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 16)
+    buf = torch.empty(B, L, 3 * D, dtype=torch.bfloat16, device=DEV)
+    d = lib.AttnDesc()
+    d.K = d.Vt = buf.data_ptr()
+    d.Q = buf.data_ptr() + 2 * 2 * D
+    d.ldq = d.ldk = 3 * D
+    d.strideQ = d.strideK = L * 3 * D
+    d.B, d.H, d.L, d.Lp, d.Lt = B, H, L, Lp, LT
+    d.q_prescaled = 1
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    d.O, d.ldo, d.strideO = d.Q, 3 * D, L * 3 * D
+    assert lib.load().pf_attention_which(C.byref(d)) == 64          # exact in-place form
+    d.O, d.ldo, d.strideO = buf.data_ptr() + 2 * 2 * D + 16 * 3 * D * 2, 3 * D, L * 3 * D   # shifted by 16 rows
+    assert lib.load().pf_attention_which(C.byref(d)) == 32
+    d.O, d.ldo, d.strideO = d.Q, D, L * D                          # same start, other leading dimension
+    assert lib.load().pf_attention_which(C.byref(d)) == 32

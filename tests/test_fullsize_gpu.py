@@ -70,6 +70,16 @@ def test_full_size_attention_properties_and_sampled_rows():
     s = s.masked_fill(~dm[:, None], float("-inf"))
     ref = torch.einsum("bhrl,bhld->bhrd", torch.softmax(s, -1), v).transpose(1, 2).reshape(B, len(rows), D)
     assert rel_l2(out[:, rows].float().cpu(), ref.cpu()) < 1e-2
+    # last-block form at the headline shape: q_row_begin = 11 648 = 91 x 128 (ODD 128-row tile): the 256-row workgroups
+    # start at row 11 520, and must neither store nor flag the 128 rows below q_row_begin (flux.py's tail form never
+    # produced their Q); rows from q_row_begin on equal the full run bit for bit
+    r0 = L - plan.n_cur
+    assert r0 == 11648 and (r0 // 128) % 2 == 1
+    tail = torch.full_like(out, 7.0)
+    ops.attention(qkv, qkv, vT, tail, 2 * D, 0, 0, 3 * D, L * 3 * D, B, H, L, Lp, LT, plan, 0.125, q_prescaled=True,
+                  ldo=D, o_bstride=L * D, q_row_begin=r0)
+    assert torch.equal(tail[:, r0:], out[:, r0:])
+    assert (tail[:, :r0].float() == 7.0).all()
     # property: constant V (per feature) -> every row returns that constant (rows of P sum to one over the visible keys)
     const = torch.linspace(-2, 2, D, device=DEV).to(torch.bfloat16)
     qkv2 = qkv.clone()
@@ -143,3 +153,64 @@ def test_full_size_forward_invariants():
     finally:
         ops.gemm_set_policy(4)
     assert rel_l2(v5.cpu(), a.cpu()) < 1e-3           # whole tiles only: the two layouts agree as they did before the split
+
+
+def test_full_size_forward_vs_oracle_one_block_of_each_kind():
+    """THE headline sequence (unit 30, stage 2: L = 15 488 = 128 text + 28 + 1 + 1 history frames + the current frame,
+    CFG batch 2, d = 1920, 30 heads) through a complete miniFLUX forward with one double-stream + one single-stream block
+    against the fp32 CPU oracle (oracle/flux_oracle.py, modeling_pyramid_flux.py:392-542) -- the length where a third of a
+    video's time is spent and where the tail-split GEMM, the 64-rows-per-wave attention pair at H = 30 and the last-block
+    row restriction all engage.  Tolerance: one forward <= 2e-2, per-block hidden states <= 1.5e-2.  The oracle
+    needs ~15 s on the GPU box's 64 host cores (its attention runs 5 heads at a time above L = 8 192)."""
+    import ctypes as C
+    from pyflow_hip import lib, ops, synth
+    from pyflow_hip.flux import FluxEngine
+    from oracle.flux_oracle import flux_forward
+    from util import round_sd
+    cfg = dict(synth.MINIFLUX, num_layers=1, num_single_layers=1)
+    sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=21, std=0.02, lively=True))
+    g = torch.Generator().manual_seed(13)
+    clips = [torch.randn(2, 16, *s_, generator=g).to(torch.bfloat16).float() for s_ in CLIPS]
+    enc = torch.randn(2, LT, 4096, generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(2, 768, generator=g)
+    t = torch.tensor([704.0, 704.0])
+    mask = _mask()
+    with torch.no_grad():
+        ref, inter = flux_forward(sd, cfg, clips, enc, mask, pooled, t, return_intermediates=True)
+    eng = FluxEngine(sd, cfg, DEV)
+    plan = eng.make_plan(CLIPS, mask)
+    assert plan.L == 15488
+    # the kernels this shape runs: persistent 256 x 256 GEMM (with its tail split: scratch is offered) for every image
+    # projection, the attention pair for the joint attention
+    so = lib.load()
+    Li = plan.L - LT
+    for M, N, K in ((Li, 3 * D, D), (Li, D, D), (Li, 4 * D, D), (Li, D, 4 * D), (plan.L, 7 * D, D), (plan.L, D, 5 * D)):
+        assert so.pf_gemm_which(C.c_int(M), C.c_int(2), C.c_int(N), C.c_int(K)) == 8, (M, N, K)
+    so.pf_gemm_workspace_bytes.restype = C.c_longlong
+    assert so.pf_gemm_workspace_bytes(C.c_int(15488), C.c_int(2), C.c_int(D), C.c_int(5 * D)) > 0
+    ad = lib.AttnDesc()
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 20)
+    ad.Q = ad.O = ws.data_ptr()
+    ad.K = ad.Vt = ws.data_ptr()
+    ad.ldq = ad.ldk = ad.ldo = 7 * D
+    ad.strideQ = ad.strideO = 15488 * 7 * D
+    ad.B, ad.H, ad.L, ad.Lp, ad.Lt, ad.q_prescaled = 2, H, plan.L, plan.Lp, LT, 1
+    ad.workspace, ad.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert so.pf_attention_which(C.byref(ad)) == 64              # the in-place form of the single blocks
+    ad.q_row_begin = plan.L - plan.n_cur
+    assert so.pf_attention_which(C.byref(ad)) == 64              # ... and of the last block's restricted rows
+    clips_d = [c.cuda() for c in clips]
+    ctx = eng.encode_context(enc)
+    dbg = {}
+    eng.skip_dead_rows = False
+    eng.forward_tokens(plan, clips_d, [704.0, 704.0], pooled, ctx, debug=dbg)
+    e_x = rel_l2(dbg["hidden_d0"].float().cpu()[:, LT:], inter["x_after_double0"])
+    e_c = rel_l2(dbg["hidden_d0"].float().cpu()[:, :LT], inter["c_after_double0"])
+    e_f = rel_l2(dbg["hidden_final"].float().cpu()[:, LT:], inter["x_final"])
+    print(f"L = 15488: image rows after the double block {e_x:.3e}, text rows {e_c:.3e}, after the single block {e_f:.3e}")
+    assert e_x < 1.5e-2 and e_c < 1.5e-2 and e_f < 2e-2
+    eng.skip_dead_rows = True                # production form: last block restricted to the current frame's rows
+    out = eng.forward(clips_d, enc, mask, pooled, t).cpu()
+    err = rel_l2(out, ref)
+    print(f"miniFLUX d=1920 H=30 L=15488 (1 double + 1 single block): forward rel-L2 vs oracle {err:.3e}")
+    assert out.shape == ref.shape and err < 2e-2

@@ -42,11 +42,13 @@ def test_encoder_vs_reference_fixture_and_oracle():
                 encoder_temporal_down_sample=g["vae_enc_cfg"]["encoder_temporal_down_sample"])
     ref = vae_encode_moments(sd, ocfg, x)
     assert post.parameters.shape == ref.shape
-    assert rel_l2(post.parameters.float().cpu(), ref) < 3e-2
-    assert rel_l2(post.parameters.float().cpu(), g["moments"].float()) < 3e-2
+    # one encoder forward, bf16 HIP vs fp32 oracle / reference fixture: the forward bound of SURVEY 8c (2e-2)
+    e_or, e_fx = rel_l2(post.parameters.float().cpu(), ref), rel_l2(post.parameters.float().cpu(), g["moments"].float())
     vae.enable_tiling()
     post_t = vae.encode(x.cuda(), tile_sample_min_size=32).latent_dist
-    assert rel_l2(post_t.parameters.float().cpu(), g["moments_tiled32"].float()) < 3e-2
+    e_tl = rel_l2(post_t.parameters.float().cpu(), g["moments_tiled32"].float())
+    print(f"tiny encoder: vs oracle {e_or:.3e}, vs reference fixture {e_fx:.3e}, tiled vs fixture {e_tl:.3e}")
+    assert e_or < 2e-2 and e_fx < 2e-2 and e_tl < 2e-2
     # sample / mode
     eps = g["posterior_eps"]
     z = post.sample(eps=eps.cuda())

@@ -55,6 +55,16 @@ def test_flux_oracle_bit_exact(ref):
               timestep_ratio=t)[0]
     o = flux_forward(m.state_dict(), rh.TINY_DIT, clips, enc, mask, pooled, t)
     assert (r - o).abs().max().item() < 1e-5
+    # the grouped-head evaluation the oracle switches to above L = 8 192 (bounded memory at the headline length,
+    # tests/test_fullsize_gpu.py) is the same function: forced here on the tiny sequence, pinned to the reference too
+    from oracle import flux_oracle
+    keep = flux_oracle.HEAD_CHUNK_ABOVE_L, flux_oracle.HEAD_CHUNK
+    flux_oracle.HEAD_CHUNK_ABOVE_L, flux_oracle.HEAD_CHUNK = 0, 1
+    try:
+        o2 = flux_forward(m.state_dict(), rh.TINY_DIT, clips, enc, mask, pooled, t)
+    finally:
+        flux_oracle.HEAD_CHUNK_ABOVE_L, flux_oracle.HEAD_CHUNK = keep
+    assert (r - o2).abs().max().item() < 1e-5
 
 
 def test_vae_oracle(ref):

@@ -8,6 +8,7 @@ namespace {
 template __global__ void attn64_kernel<2, 0>(const AArgs);
 template __global__ void attn64_kernel<2, 1>(const AArgs);
 template __global__ void attn64_kernel<2, 4>(const AArgs);
+template __global__ void attn64_kernel<2, 33>(const AArgs);
 }
 EOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -Wno-unused-value -S --cuda-device-only -o /tmp/attn64.s _inst_tmp.hip 2>&1 | grep -v "argument unused" | head -20
