@@ -271,6 +271,9 @@ def main():
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1, sp: communicator -- auto = the C-ABI RCCL communicator (pf_comm_*) when its self-test passes on "
                          "every rank, else torch.distributed")
+    ap.add_argument("--gemm-policy", type=int, action="append", default=[],
+                    help="A/B switch: pf_gemm_set_policy(value) before the model is built (e.g. -5 = no LDS-halo conv, -4 = no "
+                         "tail split); repeatable.  Not for the headline line")
     ap.add_argument("--parallelism", default="sp", choices=["sp", "replicas"],
                     help="N > 1: sp = one video across all GPUs (default), replicas = one video per GPU")
     args = ap.parse_args()
@@ -332,6 +335,10 @@ def main():
                 sp_mod._SP = None
             comm_used = comm
 
+    if args.gemm_policy:
+        from pyflow_hip import ops as ops_
+        for pol in args.gemm_policy:
+            ops_.gemm_set_policy(pol)
     H, W, temp, steps1, stepsv = WORKLOADS[args.workload]
     i2v = args.workload.startswith("c4")
     image_only = args.workload.startswith("c1")
@@ -439,9 +446,24 @@ def main():
         recs[name] = dict(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                           frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None, kernel=name, launches_timed=s["launches"],
                           avg_launch_ms=round(s["ms_total"] / s["launches"], 4), ms_timed=round(s["ms_total"], 1))
-    # dominant kernel = the one with the most device time among the sampled launches (names = rocprofv3 kernel names)
-    dom = max(recs, key=lambda n: recs[n]["ms_timed"]) if recs else None
-    roof = recs.pop(dom) if dom else None
+    # Kernel FAMILIES: template flavours of one kernel (gemm8p_kernel<false, 0 / 1 / 4>: plain / residual / GELU epilogue) are
+    # one family; the dominant family = the one with the most device time among the sampled launches.  `roofline` is that
+    # family (summed work / summed time); every flavour keeps its own entry under roofline_other_kernels.
+    def family_of(name):
+        return name.split("<")[0].split("(")[0].strip()
+    fams = {}
+    for name, r_ in recs.items():
+        f_ = fams.setdefault(family_of(name), dict(members=[], work=0.0, ms=0.0, launches=0))
+        f_["members"].append(name)
+        f_["work"] += summ[name]["work_total"]
+        f_["ms"] += summ[name]["ms_total"]
+        f_["launches"] += summ[name]["launches"]
+    families = {k: dict(bound="mfma", achieved=round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(v["work"] / (v["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), kernel=k, members=sorted(v["members"]),
+                        launches_timed=v["launches"], avg_launch_ms=round(v["ms"] / v["launches"], 4), ms_timed=round(v["ms"], 1),
+                        pflop_timed=round(v["work"] / 1e15, 3)) for k, v in fams.items()}
+    dom = max(families, key=lambda n: families[n]["ms_timed"]) if families else None
+    roof = dict(families[dom], traffic=None) if dom else None
     extra = recs
     if vae_only:
         roof, extra = None, {}
@@ -460,11 +482,18 @@ def main():
             ops.PROFILER.enabled = False
             the_vae.n_streams = keep_ns
             torch.cuda.synchronize()
-            for name, sv in ops.PROFILER.summary().items():
-                if sv["ms_total"] <= 0 or name not in ("conv3d", "gn_stats", "gn_apply"):
+            vsum = ops.PROFILER.summary()
+            conv_all = dict(launches=0, ms_total=0.0, work_total=0.0)       # the decode's conv family = all conv3d:* kernels
+            for name, sv in vsum.items():
+                if name.startswith("conv3d"):
+                    for k_ in conv_all:
+                        conv_all[k_] += sv[k_]
+            vsum = dict(vsum, conv3d=conv_all)
+            for name, sv in vsum.items():
+                if sv["ms_total"] <= 0 or not (name.startswith("conv3d") or name in ("gn_stats", "gn_apply")):
                     continue
                 rate = sv["work_total"] / (sv["ms_total"] * 1e-3)
-                hbm = name != "conv3d"
+                hbm = not name.startswith("conv3d")
                 extra["vae:" + name] = dict(
                     bound="hbm" if hbm else "mfma", achieved=round(rate / (1e9 if hbm else 1e12), 1),
                     peak=PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS, unit="GB/s" if hbm else "TFLOP/s",
@@ -509,16 +538,25 @@ def main():
     def pmc_traffic(name):
         if name in ("conv3d", "gn_stats", "gn_apply"):
             return vae_traffic(name)
-        key = {"attention": "attn64_kernel<2, 1>", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
+        if name.startswith("conv3d:"):
+            for n, v in pmv.items():
+                if name[7:].split("<")[0] in n and ("true" in n or "conv_" in n):
+                    return round(v["hbm_bytes_per_launch"])
+            return None
+        key = {"attention": "attn64_kernel<2, ", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
         key = key.replace("gemm256_kernel<128>", "gemm256_kernel<128, false").replace("gemm256_kernel<192>", "gemm256_kernel<192, false") \
                  .replace("gemm256_kernel<256>", "gemm256_kernel<256, false")
         for n, v in pm.items():
             if key in n:
                 return round(v["hbm_bytes_per_launch"])
         return None
-    for r in [roof] + list(extra.values()):
+    for r in list(extra.values()):
         if r is not None and r.get("traffic") is None:
             r["traffic"] = pmc_traffic(r["kernel"])
+    if roof is not None:      # family: launch-weighted mean of its members' per-launch traffic
+        mem = [extra[m_] for m_ in roof["members"] if m_ in extra and extra[m_].get("traffic") is not None]
+        nl_ = sum(m_["launches_timed"] for m_ in mem)
+        roof["traffic"] = round(sum(m_["traffic"] * m_["launches_timed"] for m_ in mem) / nl_) if nl_ else None
     for k_, r_ in extra.items():
         if k_.startswith("vae:") and r_.get("traffic") is not None:
             r_["traffic_note"] = (f"(2*FETCH_SIZE + WRITE_SIZE) per launch from rocprofv3 --pmc passes over the same tile-chunk "
@@ -554,8 +592,13 @@ def main():
                        "uneven 30-head map) + tile-parallel VAE decode" if use_sp
                        else f"{world} independent replicas (one video per GPU)")},
         "roofline": roof,
+        "roofline_family": families,
         "roofline_other_kernels": extra,
     }
+    if args.workload.startswith("c3") and not args.tiny_model:
+        # whole-step MFMA utilisation: ALGORITHMIC matmul work of one video (DiT GEMMs 27.98 + useful
+        # attention 13.35 + un-tiled VAE decode 4.61 PFLOP) / step time / (GPUs x dense bf16 peak)
+        res["whole_step_mfma_frac"] = round(45.94e15 * (1 if use_sp or world == 1 else world) / (dt / args.steps) / (world * PEAK_BF16_TFLOPS * 1e12), 4)
     if pipe is not None:
         res["config"]["launch_mode"] = getattr(pipe.dit, "launch_mode", "eager")
     # device memory the timed region needed (torch allocator high-water mark, max over ranks): the tiled decode runs four

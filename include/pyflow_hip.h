@@ -120,6 +120,11 @@ typedef struct {
 } pf_conv_desc;
 int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
 int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d);   /* 1 = pf_conv3d_bf16(d) accumulates d->gn_stats */
+/* which kernel pf_conv3d_bf16(d) launches: -1 conv_narrow_kernel (<= 8 filters: conv_out), -2 conv_halo128_kernel (LDS-halo
+ * direct conv: 3 x 3 x 3 taps, 128 filters, 128 / 256 input channels, frames of whole 16 x 32 patches -- the decoder's
+ * full-resolution resnets, modeling_resnet.py:115-150), 8 gemm8p_kernel, 128 / 192 / 256 gemm256_kernel<BN>, 0 the
+ * 128 x 128 implicit GEMM; -100 = the descriptor is rejected */
+int pf_conv3d_which(const pf_conv_desc* d);
 
 
 /* ------------------------------------------------------------------ attention --------------------

@@ -395,9 +395,11 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
         constexpr int SM64 = 2 * ABUF + 4 * 64 * HD * 2;
         const int grid64 = ((a.nqt + 1) / 2 - a.qt0 / 2) * a.H * a.B;
         a.wgflags = (int*)d->workspace;
-        PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 1>), SM64);
+        // FAST | MMSUM (33): row sums on the matrix pipe, +1.5 % (L = 15 488) ... +3 % (L = 3 008) over the v_add_f32 sums
+        // (mode 1) in the same-box A/B of profiles/r04_attention_rowsum_variants.log; the v_dot2c / v_pk_add forms lose 2-3 %
+        PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33>), SM64);
         PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
-        hipLaunchKernelGGL((attn64_kernel<2, 1>), dim3(grid64), dim3(256), SM64, stream, a);
+        hipLaunchKernelGGL((attn64_kernel<2, 33>), dim3(grid64), dim3(256), SM64, stream, a);
         hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
         hipError_t e64 = hipGetLastError();
         if (e64 != hipSuccess) return pf_set_err(hipGetErrorString(e64));

@@ -271,6 +271,8 @@ long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
 int pf_conv_narrow_launch(const pf_conv_desc* d, hipStream_t stream);
+bool pf_conv_halo_supports(const pf_conv_desc* d);                         // convhalo.hip: 3x3x3, 128 filters, 128 / 256 input channels
+int pf_conv_halo_launch(const pf_conv_desc* d, double* gn_stats, int gn_C, hipStream_t stream);
 
 // tile-width policy of the 256-row ping-pong kernels: 0 (auto, default) | 128 | 192 | 256 (that width when it divides N) | -1 (never)
 static int g_gemm256_force = 0;
@@ -278,6 +280,7 @@ static int gemm256_force() { return g_gemm256_force; }
 // gemm8p (persistent 256 x 256 tiles): 1 = whenever legal (policy 8), 0 = automatic, -1 = never (policy -8)
 static int g_gemm8p_mode = 0;
 static bool g_narrow_enabled = true;         // pf_gemm_set_policy(-3) / (3): never / again the narrow-N conv kernel
+static bool g_halo_enabled = true;           // pf_gemm_set_policy(-5) / (5): never / again the LDS-halo direct conv (N = 128 layers)
 static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
 static bool use_gemm8p(int M, int batch, int N, int K) {
@@ -295,9 +298,10 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 2 || force == -2) { g_splitk_enabled = force > 0; return 0; }
     if (force == 3 || force == -3) { g_narrow_enabled = force > 0; return 0; }
     if (force == 4 || force == -4) { pf_gemm8p_set_tail_split(force > 0); return 0; }
+    if (force == 5 || force == -5) { g_halo_enabled = force > 0; return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 3, -3, 4, -4, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 3, -3, 4, -4, 5, -5, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
@@ -392,9 +396,11 @@ static void conv_args(const pf_conv_desc* d, Args& a) {
                     d->in_sh > 0 ? d->in_sh : 1, d->in_sw > 0 ? d->in_sw : 1, d->in_st > 0 ? d->in_st : 1};
     a.om = OutMap{1, d->H, d->W_, d->st, d->sh, d->sw, d->Cg, d->Hop, d->Wop, d->out_base_off, d->Cout_pitch, d->out_t_shift};
 }
-// -1 = conv_narrow_kernel, 8 = gemm8p_kernel<true, 0>, 128 / 192 / 256 = gemm256_kernel<BN, true>, 0 = gemm_kernel<true>
+// -1 = conv_narrow_kernel, -2 = conv_halo128_kernel, 8 = gemm8p_kernel<true, 0>, 128 / 192 / 256 = gemm256_kernel<BN, true>,
+// 0 = gemm_kernel<true>
 static int conv_route(const pf_conv_desc* d, const Args& a) {
     if (g_narrow_enabled && pf_conv_narrow_supports(d)) return -1;
+    if (g_halo_enabled && gemm256_force() == 0 && pf_conv_halo_supports(d)) return -2;
     if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) return 8;
     return pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force());
 }
@@ -403,6 +409,7 @@ static int conv_route(const pf_conv_desc* d, const Args& a) {
 static bool conv_fuses_gn_stats(const pf_conv_desc* d, const Args& a, int route) {
     if (!d->gn_stats || d->gn_C <= 0 || a.n_valid > d->gn_C) return false;
     if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->out_t_shift != 0 || (d->flags & PF_GEMM_OUT_F32)) return false;
+    if (route == -2) return true;                  // the halo kernel's tiles never straddle a frame
     if (((long long)d->H * d->W_) % 256 != 0) return false;
     return route == 128 || route == 256;
 }
@@ -413,6 +420,12 @@ static const char* conv_check(const pf_conv_desc* d) {
     if (d->T <= 0 || d->H <= 0 || d->W_ <= 0) return "pf_conv3d_bf16: empty problem";
     if ((long long)d->T * d->H * d->W_ > 0x7fffffffll) return "pf_conv3d_bf16: more than 2^31 output pixels";
     return nullptr;
+}
+extern "C" int pf_conv3d_which(const pf_conv_desc* d) {
+    if (conv_check(d)) return -100;
+    Args a{};
+    conv_args(d, a);
+    return conv_route(d, a);
 }
 extern "C" int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d) {
     if (conv_check(d)) return 0;
@@ -427,6 +440,13 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
     conv_args(d, a);
     const int route = conv_route(d, a);
     if (route == -1) return pf_conv_narrow_launch(d, stream);
+    if (route == -2) {
+        const bool st = conv_fuses_gn_stats(d, a, route);
+        pf_conv_halo_launch(d, st ? d->gn_stats : nullptr, d->gn_C, stream);
+        hipError_t eh = hipGetLastError();
+        if (eh != hipSuccess) return set_err(hipGetErrorString(eh));
+        return 0;
+    }
     if (d->Cg % 8 || d->Cout_pitch % 8) return set_err("pf_conv3d_bf16: Cg / Cout_pitch must be multiples of 8");
     if (conv_fuses_gn_stats(d, a, route)) { a.gn_stats = d->gn_stats; a.gn_C = d->gn_C; }
     if (route == 8) {

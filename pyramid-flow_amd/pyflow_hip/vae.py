@@ -183,7 +183,12 @@ def conv(src, dst, cw, Tc, st=1, sh=1, sw=1, res=None, t_shift=0, dst_raw=None, 
             d.gn_stats = gn_stats.data_ptr() + f0 * dst.C * 2 * 8
             d.gn_C = dst.C
             fused.append(bool(lib.pf_conv3d_fuses_gn_stats(C.byref(d))))
-        ops.PROFILER.launch("conv3d", 2.0 * nf * (src.H // down) * (src.W // down) * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
+        name = "conv3d"
+        if ops.PROFILER.enabled:          # attribute the launch to the kernel rocprofv3 will name (pf_conv3d_which)
+            route = int(lib.pf_conv3d_which(C.byref(d)))
+            name = "conv3d:" + {-2: "conv_halo128_kernel", -1: "conv_narrow_kernel", 8: "gemm8p_kernel<true, 0>",
+                                0: "gemm_kernel<true>"}.get(route, f"gemm256_kernel<{route}, true>")
+        ops.PROFILER.launch(name, 2.0 * nf * (src.H // down) * (src.W // down) * cw.n_valid * cw.kt * cw.kh * cw.kw * src.C,
                             lambda: check(lib.pf_conv3d_bf16(C.byref(d), stream())))
 
     fused = []

@@ -55,8 +55,10 @@ def _which(plan, B, L, Lp, prescaled=True):
     from pyflow_hip import lib, ops
     d = lib.AttnDesc()
     ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 16)
-    d.Q = d.K = d.Vt = d.O = ws.data_ptr()
+    d.Q = d.K = d.Vt = ws.data_ptr()
+    d.O = ws.data_ptr() + (1 << 40)               # an output range that does not touch Q (pf_attention_which only compares addresses)
     d.ldq = d.ldk = 3 * D
+    d.strideQ = d.strideK = L * 3 * D
     d.ldo = D
     d.strideO = L * D
     d.B, d.H, d.L, d.Lp, d.Lt = B, H, L, Lp, LT
