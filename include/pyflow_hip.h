@@ -27,8 +27,8 @@ typedef struct ihipStream_t* pf_stream_t; /* == hipStream_t */
 const char* pf_last_error(void);
 /* ABI version of THIS header.  pf_version() returns the version the library was built with; a caller compares the two
  * before its first launch (a descriptor struct that grew -- 2 -> 3: pf_attn_desc.workspace / workspace_bytes,
- * pf_conv_desc.gn_stats / gn_C -- would otherwise be read past its end). */
-#define PF_ABI_VERSION 3
+ * pf_conv_desc.gn_stats / gn_C; 3 -> 4: pf_gemm_desc.qk_* -- would otherwise be read past its end). */
+#define PF_ABI_VERSION 4
 int pf_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: 0 pf_gemm_desc, 1 pf_conv_desc, 2 pf_attn_desc,
  * 3 pf_attn_small_desc (-1 otherwise) -- lets a foreign-language binding (ctypes / cgo / JNI struct mirrors) verify its
@@ -68,6 +68,18 @@ typedef struct {
      * Bitwise repeatable; differs from the scratch-less result in fp32 summation order only. */
     void* workspace;
     long long workspace_bytes;
+    /* ABI 4 -- optional QK-RMSNorm + RoPE of the projection's K and Q column blocks, applied to the bf16 result exactly as
+     * pf_qk_norm_rope would in a separate pass (RMSNorm over each 64-wide head with gains qk_wk / qk_wq, eps qk_eps:
+     * modeling_normalization.py:66-79; adjacent-pair rotation by qk_rope, flux_block.py:34-39; Q additionally * qk_q_scale):
+     * the K block is columns [qk_k_col0, qk_k_col0 + qk_d), the Q block [qk_q_col0, qk_q_col0 + qk_d) of C (a start < 0 =
+     * that block is not part of this GEMM); row r of every batch entry uses table row qk_row0 + r of qk_rope
+     * ([rows][32][cos, sin] fp32).  qk_d = 0: none.  Where the persistent 256 x 256 kernel runs, this happens in its
+     * epilogue from the accumulators (no second pass over [rows][3 d]: flux_block.py:846-858 costs two extra HBM passes
+     * per block otherwise); for any other kernel choice pf_gemm_bf16 launches the separate pass itself.  Same bits either
+     * way.  Requires bf16 output, no residual, qk_d / column starts multiples of 64. */
+    const float* qk_rope; const float* qk_wq; const float* qk_wk;
+    int qk_d, qk_q_col0, qk_k_col0, qk_row0;
+    float qk_eps, qk_q_scale;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
 /* bytes of pf_gemm_desc.workspace this problem can use (0 = it never splits) */

@@ -10,7 +10,7 @@ int pf_set_err(const char* m) {
 }
 
 extern "C" const char* pf_last_error(void) { return g_err; }
-// 3: pf_attn_desc grew (workspace, workspace_bytes) and pf_conv_desc grew (gn_stats, gn_C) in round 3 -- a caller built against
+// 4: pf_gemm_desc grew (qk_*); 3: pf_attn_desc grew (workspace, workspace_bytes) and pf_conv_desc grew (gn_stats, gn_C) in round 3 -- a caller built against
 // a version-2 header passes shorter structs; check pf_version() == PF_ABI_VERSION (and pf_struct_size) before the first call
 extern "C" int pf_version(void) { return PF_ABI_VERSION; }
 extern "C" int pf_struct_size(int which) {

@@ -91,6 +91,29 @@ PF_DEVICE void act8(float* v, int flags) {
     }
 }
 
+// QK-RMSNorm + RoPE on 8 consecutive channels of one (token, head) unit (modeling_normalization.py:66-79,
+// flux_block.py:34-39) -- ONE definition shared by the standalone pass (elementwise.hip: qk_norm_rope_kernel) and the
+// QKV GEMM's epilogue (gemm8p.hip, flavour 8), every multiply-add spelled out, so that the two produce the same bits:
+// sum of squares of the bf16 values (in channel order), then per pair (x0, x1) = v * r * w, rotated by (cos, sin), * osc.
+PF_DEVICE float qk_sumsq8(const float* v) {
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[e], v[e], ss);
+    return ss;
+}
+PF_DEVICE float qk_rstd(float ss64, float eps) { return rsqrtf(__builtin_fmaf(ss64, 1.f / 64.f, eps)); }
+// w: the 8 gains of these channels; cs: (cos, sin) of their 4 pairs
+PF_DEVICE void qk_rope8(const float* v, float r, const float* w, const float* cs, float osc, float* o) {
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const float x0 = (v[2 * pr] * r) * w[2 * pr];
+        const float x1 = (v[2 * pr + 1] * r) * w[2 * pr + 1];
+        const float c = cs[2 * pr], s = cs[2 * pr + 1];
+        o[2 * pr] = __builtin_fmaf(c, x0, -(s * x1)) * osc;
+        o[2 * pr + 1] = __builtin_fmaf(s, x0, c * x1) * osc;
+    }
+}
+
 PF_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): gives each XCD a

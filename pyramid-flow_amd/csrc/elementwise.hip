@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* x, bf16_t* y,
     }
 }
 
-// 8 lanes per (token, head, q|k) unit of 64 elements.
+// 8 lanes per (token, head, q|k) unit of 64 elements.  q_off / k_off < 0: that block is absent (the last-block form of
+// the engines produces K and Q by separate GEMMs).  Arithmetic: qk_sumsq8 / qk_rstd / qk_rope8 (common.h), shared with the
+// QKV GEMM's fused epilogue.
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, long long bstride, int q_off, int k_off,
                                                            const float* wq_img, const float* wk_img,
                                                            const float* wq_txt, const float* wk_txt,
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, 
     const long long total = (long long)B * L * H * 2;
     if (unit >= total) return;
     const int which = unit & 1;
+    if ((which ? k_off : q_off) < 0) return;
     const long long u2 = unit >> 1;
     const int h = u2 % H;
     const long long tokb = u2 / H;
@@ -94,25 +97,17 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* qkv, int ld, 
     bf16_t* ptr = qkv + (long long)b * bstride + (long long)tok * ld + (which ? k_off : q_off) + h * hstride + sub * 8;
     float v[8];
     unpack8(*(const u32x4_t*)ptr, v);
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+    float ss = qk_sumsq8(v);
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
     ss += __shfl_xor(ss, 4);
-    const float r = rsqrtf(ss * (1.f / 64.f) + eps);
+    const float r = qk_rstd(ss, eps);
     const float* w = (tok < Lt) ? (which ? wk_txt : wq_txt) : (which ? wk_img : wq_img);
     const float* cs = rope + ((long long)tok * 32 + sub * 4) * 2;   // [L][32][cos,sin]
-    const float osc = which ? 1.f : q_scale;
-    float o[8];
+    float w8[8], cs8[8], o[8];
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {
-        const float x0 = v[2 * pr] * r * w[sub * 8 + 2 * pr];
-        const float x1 = v[2 * pr + 1] * r * w[sub * 8 + 2 * pr + 1];
-        const float c = cs[2 * pr], s = cs[2 * pr + 1];
-        o[2 * pr] = (c * x0 - s * x1) * osc;
-        o[2 * pr + 1] = (s * x0 + c * x1) * osc;
-    }
+    for (int e = 0; e < 8; ++e) { w8[e] = w[sub * 8 + e]; cs8[e] = cs[e]; }
+    qk_rope8(v, r, w8, cs8, which ? 1.f : q_scale, o);
     *(u32x4_t*)ptr = pack8(o);
 }
 
@@ -314,7 +309,8 @@ extern "C" int pf_qk_norm_rope(void* qkv, int ld, long long bstride, int q_off, 
                                hipStream_t stream) {
     if (!qkv || !wq_img || !wk_img || !rope) return pf_set_err("pf_qk_norm_rope: null operand");
     if (head_stride <= 0) head_stride = 64;
-    if (ld % 8 || q_off % 8 || k_off % 8 || head_stride % 8) return pf_set_err("pf_qk_norm_rope: misaligned layout");
+    if (ld % 8 || (q_off >= 0 && q_off % 8) || (k_off >= 0 && k_off % 8) || head_stride % 8)
+        return pf_set_err("pf_qk_norm_rope: misaligned layout");
     const long long threads = (long long)B * L * H * 2 * 8;
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
                        (bf16_t*)qkv, ld, bstride, q_off, k_off, wq_img, wk_img, wq_txt ? wq_txt : wq_img,

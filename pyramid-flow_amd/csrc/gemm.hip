@@ -341,20 +341,41 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     a.out_scale = 1.f; a.n_valid = d->N;
     if (a.gelu_from % 8) return set_err("pf_gemm_bf16: gelu_from must be a multiple of 8");
     a.group_m = 0;
+    const bool qk = d->qk_d > 0;
+    if (qk) {
+        if (!d->qk_rope || !d->qk_wq || !d->qk_wk) return set_err("pf_gemm_bf16: qk_d > 0 needs qk_rope / qk_wq / qk_wk");
+        if ((d->qk_d % 64) || (d->qk_q_col0 >= 0 && d->qk_q_col0 % 64) || (d->qk_k_col0 >= 0 && d->qk_k_col0 % 64) ||
+            (d->qk_q_col0 >= 0 && d->qk_q_col0 + d->qk_d > d->N) || (d->qk_k_col0 >= 0 && d->qk_k_col0 + d->qk_d > d->N))
+            return set_err("pf_gemm_bf16: the QK blocks must be 64-column aligned and inside N");
+        if (d->flags & (PF_GEMM_GATE_RES | PF_GEMM_OUT_F32)) return set_err("pf_gemm_bf16: QK epilogue needs a plain bf16 output");
+        if (a.gelu_from < d->N && ((d->qk_q_col0 >= 0 && a.gelu_from < d->qk_q_col0 + d->qk_d) || (d->qk_k_col0 >= 0 && a.gelu_from < d->qk_k_col0 + d->qk_d)))
+            return set_err("pf_gemm_bf16: the activation columns overlap a QK block");
+        a.qk_rope = d->qk_rope; a.qk_wq = d->qk_wq; a.qk_wk = d->qk_wk;
+        a.qk_d = d->qk_d; a.qk_q0 = d->qk_q_col0; a.qk_k0 = d->qk_k_col0; a.qk_row0 = d->qk_row0;
+        a.qk_eps = d->qk_eps; a.qk_qs = d->qk_q_scale;
+    }
+    // the separate pass for every kernel choice whose epilogue cannot do it (same arithmetic: common.h qk_rope8)
+    auto qk_pass = [&]() -> int {
+        return pf_qk_norm_rope(d->C, d->ldc, d->strideC, d->qk_q_col0, d->qk_k_col0, d->qk_wq, d->qk_wk, nullptr, nullptr,
+                               d->qk_rope + (long long)d->qk_row0 * 64, d->batch, d->M, 0, d->qk_d / 64, d->qk_eps,
+                               d->qk_q_scale, 64, stream);
+    };
     const bool g8 = use_gemm8p(d->M, d->batch, d->N, d->K) && pf_gemm8p_supports(a, false);
     if (!g8 && !bn256 && d->N % BN != 0)
         return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (g8) {
-        pf_gemm8p_launch(a, false, stream, d->workspace, d->workspace_bytes);
+        // (with a QK epilogue the tail tiles are not split: gemm8p_tail_kernel applies no norm / rotation)
+        pf_gemm8p_launch(a, false, stream, qk ? nullptr : d->workspace, qk ? 0 : d->workspace_bytes);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
         return 0;
     }
+    a.qk_d = 0;                                   // every other kernel: plain epilogue, then the separate pass
     if (const int bn = bn256) {
         pf_gemm256_launch(a, bn, false, stream);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) return set_err(hipGetErrorString(e2));
-        return 0;
+        return qk ? qk_pass() : 0;
     }
     int grid = (d->N / BN) * ((d->M + BM - 1) / BM) * d->batch;
     // skinny problems (the 128-row text stream, the prompt encoders): < 128 workgroups, each a chain of K / 64 dependent
@@ -380,7 +401,7 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(hipGetErrorString(e));
-    return 0;
+    return qk ? qk_pass() : 0;
 }
 
 // ---- CausalConv3d: one routing decision shared by the launch and by pf_conv3d_fuses_gn_stats

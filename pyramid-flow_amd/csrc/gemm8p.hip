@@ -310,11 +310,45 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     //      code that missed the instruction cache once per tile (measured: 13 % of a K = 1920 tile).
     //      Order: request bias / gate / the residual pieces, drain the vector-memory queue ONCE (this also retires
     //      every DMA issued so far, see the main loop), then fp32 math and one 16-byte store per (row fragment, half).
-    constexpr bool E_RES = (EPI & 1) != 0, E_F32 = (EPI & 2) != 0, E_ACT = (EPI & 4) != 0;
+    // Flavour 8 (QK): the wave tiles that lie in the K or the Q column block (64 columns = one head: wave-uniform) apply
+    // QK-RMSNorm + RoPE to the bf16-rounded result before storing it -- the arithmetic of pf_qk_norm_rope (common.h:
+    // qk_sumsq8 / qk_rstd / qk_rope8), the same bits as the separate pass.  A row's 64 channels of a head sit in 4 lanes
+    // (fq = 0..3) x 2 column halves x 8: sum of squares = per half in channel order, lanes xor 16, xor 32, then the two
+    // halves -- the pairwise tree of the separate kernel's 8 sub-lanes.  The (cos, sin) rows and the gains are loaded in
+    // batches of QFB row fragments per column half (all loads of a batch before its one drain, as for the residual).
+    constexpr bool E_RES = (EPI & 1) != 0, E_F32 = (EPI & 2) != 0, E_ACT = (EPI & 4) != 0, E_QK = (EPI & 8) != 0;
+    static_assert(!E_QK || (!E_RES && !E_F32 && !CONV), "the QK epilogue is a form of the plain / GELU flavour");
     auto epilogue_tile = [&](int seq) {
         const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
         const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
         const bool mapped = CONV && p.om.mode == 1;
+        // 0 = not a QK wave tile, 1 = K block, 2 = Q block (scalar)
+        int qk_reg = 0;
+        if (E_QK) {
+            if (p.qk_k0 >= 0 && wave_n0 >= p.qk_k0 && wave_n0 < p.qk_k0 + p.qk_d) qk_reg = 1;
+            else if (p.qk_q0 >= 0 && wave_n0 >= p.qk_q0 && wave_n0 < p.qk_q0 + p.qk_d) qk_reg = 2;
+        }
+        float qk_r[8];                                          // 1 / rms of the wave's rows (row fragment f, row frow)
+        if (E_QK) {
+            if (qk_reg) {
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    float ssh[2];
+#pragma unroll
+                    for (int hsel = 0; hsel < 2; ++hsel) {
+                        float v[8], vb[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = acc[f][2 * hsel][r]; v[4 + r] = acc[f][2 * hsel + 1][r]; }
+                        unpack8(pack8(v), vb);                  // the values the separate pass would read back
+                        float ss = qk_sumsq8(vb);
+                        ss += __shfl_xor(ss, 16);
+                        ss += __shfl_xor(ss, 32);
+                        ssh[hsel] = ss;
+                    }
+                    qk_r[f] = qk_rstd(ssh[0] + ssh[1], p.qk_eps);
+                }
+            }
+        }
         // output element offset of (row m, column n); false = nothing to store for this row
         auto out_off = [&](int m, int n, long long& coff) -> bool {
             if (mapped) {
@@ -372,11 +406,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         u32x4_t outp[2][8];
         // row fragments per batch: the residual flavour loads a column half's 8 residual pieces, waits once, converts them
         // (two drains per tile; 4-fragment batches = four drains measured 0.5-2.5 % slower)
-        constexpr int FB = 8;
+        constexpr int FB = E_QK ? 4 : 8;
 #pragma unroll
         for (int hsel = 0; hsel < 2; ++hsel) {
             if (E_RES) load_col_params(hsel);
             const int n = ncol[hsel];
+            f32x4_t qw0, qw1;                                   // QK: gains of this lane's 8 channels of the head
+            if (E_QK) {
+                if (qk_reg) {
+                    const float* w_ = (qk_reg == 1 ? p.qk_wk : p.qk_wq) + 32 * hsel + 8 * fq;
+                    qw0 = *(const f32x4_t*)w_;
+                    qw1 = *(const f32x4_t*)(w_ + 4);
+                }
+            }
             // wave-uniform (gelu_from is a multiple of 32, pf_gemm8p_supports): the column halves left of gelu_from skip
             // the activation's VALU work instead of computing and discarding it
             const bool do_act = E_ACT && (wave_n0 + 32 * hsel) >= p.gelu_from;
@@ -399,8 +441,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         }
                     }
                 }
-                if ((hsel == 0 && f0 == 0) || E_RES) {
-                    // drains the DMA queue (see the main loop) and, for the residual flavour, this batch's pieces
+                f32x4_t qcs[FB][2];                             // QK: (cos, sin) of this lane's 4 pairs, per row fragment
+                if (E_QK) {
+                    if (qk_reg) {
+#pragma unroll
+                        for (int f = 0; f < FB; ++f) {
+                            const int m = wave_m0 + 16 * (f0 + f) + frow;
+                            const float* cs_ = p.qk_rope + ((long long)(p.qk_row0 + (m < p.M ? m : p.M - 1)) * 64 + 32 * hsel + 8 * fq);
+                            qcs[f][0] = *(const f32x4_t*)cs_;
+                            qcs[f][1] = *(const f32x4_t*)(cs_ + 4);
+                        }
+                    }
+                }
+                if ((hsel == 0 && f0 == 0) || E_RES || (E_QK && qk_reg)) {
+                    // drains the DMA queue (see the main loop) and, for the residual / QK flavours, this batch's pieces
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PF_FENCE();
                 }
@@ -421,6 +475,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         if (do_act) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+                        }
+                    }
+                    if (E_QK) {
+                        if (qk_reg) {
+                            float vb[8], w8[8], cs8[8];
+                            unpack8(pack8(v), vb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                w8[e] = qw0[e]; w8[4 + e] = qw1[e];
+                                cs8[e] = qcs[fi][0][e]; cs8[4 + e] = qcs[fi][1][e];
+                            }
+                            qk_rope8(vb, qk_r[f], w8, cs8, qk_reg == 2 ? p.qk_qs : 1.f, v);
                         }
                     }
                     if (E_RES) {
@@ -690,6 +756,7 @@ int pf_gemm8p_launch(const Args& a_in, bool conv, hipStream_t stream, void* ws, 
     const Args& a = a_in;
     const bool res = (a.flags & PF_GEMM_GATE_RES) != 0, f32 = (a.flags & PF_GEMM_OUT_F32) != 0, act = a.gelu_from < a.N;
     if (conv) return launch<true, 0>(a, stream, nullptr, 0);   // conv + shortcut add stays on gemm256 (pf_gemm8p_supports)
+    if (a.qk_d > 0) return launch<false, 12>(a, stream, nullptr, 0);      // validated by pf_gemm_bf16: no residual / fp32 output
     if (res) return launch<false, 1>(a, stream, ws, ws_bytes);
     if (f32) return launch<false, 2>(a, stream, ws, ws_bytes);
     if (act) return launch<false, 4>(a, stream, ws, ws_bytes);

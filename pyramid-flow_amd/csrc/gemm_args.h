@@ -38,6 +38,10 @@ struct Args {
     float* part;             //   partial sums part[((s * batch + b) * M + m) * N + n] instead of running the epilogue
                              // gemm8p: ksplit = workgroups of the main launch, part = scratch of the tail split (parked sums),
     int tail_ov;             //   tail_ov = the split's fixed cost in K-tile periods (gemm8p.hip: tail_plan)
+    // QK-RMSNorm + RoPE of the K / Q column blocks in the epilogue (gemm8p flavour 8; pf_gemm_desc.qk_*): qk_d = 0 -> none
+    const float* qk_rope; const float* qk_wq; const float* qk_wk;
+    int qk_d, qk_q0, qk_k0, qk_row0;
+    float qk_eps, qk_qs;
     double* gn_stats;        // conv kernels of gemm256.hip: [frame][gn_C][2] (sum, sum of squares) of the OUTPUT, accumulated in
     int gn_C;                //   the epilogue for the GroupNorm that reads it (nullptr = none)
     ConvGeom cg; OutMap om;

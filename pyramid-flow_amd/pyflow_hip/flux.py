@@ -200,6 +200,7 @@ class FluxEngine(DeviceModuleAPI):
         self._mod_cache = None
         self.overlap_text = True        # text stream of the double blocks on a side HIP stream
         self.skip_dead_rows = True      # last block: Q / MLP / attention / proj_out only for the current frame's rows
+        self.fuse_qk = True             # QK-RMSNorm + RoPE inside the K|V|Q projections (pf_gemm_desc.qk_*); False = separate pass
         self._side = None
         # how the ~300 launches of the blocks + head of one forward reach the device (cmdlist.py):
         #   "eager": one ctypes call per launch;  "list": recorded once per plan, re-issued from C by one call;
@@ -327,7 +328,7 @@ class FluxEngine(DeviceModuleAPI):
             # structure, the row restriction of the last block, and the GEMM dispatch policy / split-K state in force
             # when the descriptors were recorded (pf_gemm_set_policy picks kernels at record time)
             key = (id(self), self._ws_gen, self.overlap_text, self.skip_dead_rows, self.launch_mode != "list",
-                   ops.POLICY_GEN)
+                   ops.POLICY_GEN, self.fuse_qk)
             ent = getattr(plan, "_launch_list", None)
             if ent is not None and ent[0] == key:
                 break
@@ -466,6 +467,10 @@ class FluxEngine(DeviceModuleAPI):
             tail = pre_only and skip_dead and not sgl and n_cur < L_img
             r0 = L - n_cur if tail else Lt                      # first image row that is computed in full
             n_act = L - r0
+            # QK-RMSNorm + RoPE (flux_block.py:846-858): the image rows' K / Q blocks leave the projection's epilogue normed
+            # and rotated (pf_gemm_desc.qk_*); the 128 text rows get the separate pass on their own stream
+            fuse = self.fuse_qk
+            qk_img = dict(rope=plan.rope, wq=blk["norm_q"], wk=blk["norm_k"], d=d, eps=w.qk_eps, q_scale=qs) if fuse else None
             with on_side():
                 if pre_only:          # AdaLayerNormContinuous: (scale, shift) = chunks 0, 1 of the 2d modulation
                     ln(Lt, 0, mb + 7 * d, mb + 6 * d)
@@ -473,18 +478,26 @@ class FluxEngine(DeviceModuleAPI):
                     ln(Lt, 0, mb + 6 * d, mb + 7 * d)
                 ops.gemm(xn, blk["kvq_txt"][0], big, Lt, (2 if tail else 3) * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1],
                          batch=B, strideA=Ld, strideC=L3, workspace=ws_txt)
+                if fuse:              # rows [0, Lt) with the text stream's gains (norm_added_q / k), K only in the tail form
+                    ops.qk_norm_rope(big, 3 * d, L3, -1 if tail else 2 * d, 0, blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"],
+                                     blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"], None, None,
+                                     plan.rope, B, Lt, 0, H, q_scale=qs, eps=w.qk_eps)
             ln(L_img, Lt * d, mb + 0, mb + d)
             if tail:
                 ops.gemm(xn, blk["kvq_img"][0], big, L_img, 2 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, tail_workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, tail_workspace=None if fuse else ws_img,
+                         qk=dict(qk_img, k_col0=0, row0=Lt) if fuse else None)
                 ops.gemm(xn, blk["kvq_img"][0], big, n_act, d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=r0 * d, c_off=r0 * 3 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d, tail_workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=r0 * d, c_off=r0 * 3 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d,
+                         tail_workspace=None if fuse else ws_img, qk=dict(qk_img, q_col0=0, row0=r0) if fuse else None)
             else:
                 ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, tail_workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, tail_workspace=None if fuse else ws_img,
+                         qk=dict(qk_img, k_col0=0, q_col0=2 * d, row0=Lt) if fuse else None)
             join(1, 0)
-            ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
-                             blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
+            if not fuse:
+                ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
+                                 blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
             ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
                           q_row_begin=r0 if tail else 0)
@@ -526,12 +539,16 @@ class FluxEngine(DeviceModuleAPI):
                 # modeling_pyramid_flux.py:380).  K and V are still needed for every row, but Q, the MLP branch,
                 # the attention rows and proj_out only for the last n_cur rows -- identical values, less work.
                 r0 = L - n_cur
+                fuse = self.fuse_qk
+                qk_s = dict(rope=plan.rope, wq=blk["norm_q"], wk=blk["norm_k"], d=d, eps=w.qk_eps, q_scale=qs) if fuse else None
                 ops.gemm(xn, blk["kvqm"][0], big, L, 2 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, tail_workspace=ws_img)
+                         strideC=L7, tail_workspace=None if fuse else ws_img, qk=dict(qk_s, k_col0=0) if fuse else None)
                 ops.gemm(xn, blk["kvqm"][0], big, n_cur, 5 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, gelu_from=d, a_off=r0 * d, c_off=r0 * 7 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d, tail_workspace=ws_img)
-                ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H,
-                                 q_scale=qs, eps=w.qk_eps)
+                         strideC=L7, gelu_from=d, a_off=r0 * d, c_off=r0 * 7 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d,
+                         tail_workspace=None if fuse else ws_img, qk=dict(qk_s, q_col0=0, row0=r0) if fuse else None)
+                if not fuse:
+                    ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H,
+                                     q_scale=qs, eps=w.qk_eps)
                 ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
                 ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
                               q_row_begin=r0)
@@ -539,9 +556,13 @@ class FluxEngine(DeviceModuleAPI):
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
                          flags=GEMM_GATE_RES, a_off=r0 * 7 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, tail_workspace=ws_img)
                 continue
+            fuse = self.fuse_qk
             ops.gemm(xn, blk["kvqm"][0], big, L, 7 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                     strideC=L7, gelu_from=3 * d, tail_workspace=ws_img)
-            ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H, q_scale=qs)
+                     strideC=L7, gelu_from=3 * d, tail_workspace=None if fuse else ws_img,
+                     qk=dict(rope=plan.rope, wq=blk["norm_q"], wk=blk["norm_k"], d=d, eps=w.qk_eps, q_scale=qs, k_col0=0,
+                             q_col0=2 * d) if fuse else None)
+            if not fuse:
+                ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H, q_scale=qs)
             ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
             ops.gemm(big, blk["out"][0], hidden, L, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,

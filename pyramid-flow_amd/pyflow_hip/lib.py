@@ -22,7 +22,10 @@ class GemmDesc(C.Structure):
                 ("ldc", C.c_int), ("ldr", C.c_int),
                 ("strideA", C.c_longlong), ("strideC", C.c_longlong), ("strideR", C.c_longlong),
                 ("gate_stride", C.c_int), ("batch", C.c_int), ("gelu_from", C.c_int), ("flags", C.c_int),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
+                ("qk_rope", C.c_void_p), ("qk_wq", C.c_void_p), ("qk_wk", C.c_void_p),
+                ("qk_d", C.c_int), ("qk_q_col0", C.c_int), ("qk_k_col0", C.c_int), ("qk_row0", C.c_int),
+                ("qk_eps", C.c_float), ("qk_q_scale", C.c_float)]
 
 
 class ConvDesc(C.Structure):
@@ -59,7 +62,7 @@ class AttnSmallDesc(C.Structure):
                 ("bias", C.c_void_p), ("key_mask", C.c_void_p), ("causal", C.c_int), ("scale", C.c_float)]
 
 
-ABI_VERSION = 3          # PF_ABI_VERSION of include/pyflow_hip.h
+ABI_VERSION = 4          # PF_ABI_VERSION of include/pyflow_hip.h
 GEMM_GATE_RES = 1
 GEMM_OUT_F32 = 2
 GEMM_ACT_QUICK_GELU = 4

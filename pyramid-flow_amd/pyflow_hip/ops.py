@@ -46,12 +46,14 @@ RECORDER = None      # a cmdlist.CommandList while a launch list is being record
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
-         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None, tail_workspace=None):
+         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None, tail_workspace=None, qk=None):
     """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res.  workspace: fp32 scratch tensor that lets
     a skinny problem split its K range and a large one split its tail tiles (pf_gemm_desc.workspace); must not be
     shared by overlapping launches.  tail_workspace: the same, but handed over only to problems that run the persistent
     256 x 256 kernel (pf_gemm_which == 8): the compute stream's scratch, which leaves the summation order of small
-    problems what it is without scratch."""
+    problems what it is without scratch.
+    qk: dict(rope, wq, wk, d, q_col0, k_col0, row0, eps, q_scale) -- QK-RMSNorm + RoPE of the K / Q column blocks of C as part
+    of this GEMM (pf_gemm_desc.qk_*: in the persistent kernel's epilogue, else by the library's separate pass)."""
     lib = L.load()
     esz_c = 4 if (flags & GEMM_OUT_F32) else 2
     d = GemmDesc()
@@ -69,6 +71,10 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
         workspace = tail_workspace
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if qk is not None:
+        d.qk_rope, d.qk_wq, d.qk_wk = qk["rope"].data_ptr(), qk["wq"].data_ptr(), qk["wk"].data_ptr()
+        d.qk_d, d.qk_q_col0, d.qk_k_col0, d.qk_row0 = qk["d"], qk.get("q_col0", -1), qk.get("k_col0", -1), qk.get("row0", 0)
+        d.qk_eps, d.qk_q_scale = qk.get("eps", 1e-6), qk.get("q_scale", 1.0)
     rec = RECORDER
     if rec is not None:
         check(lib.pf_cmdlist_gemm(rec.h, C.byref(d), C.c_int(rec.slot)))
@@ -76,7 +82,7 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     if PROFILER.enabled:      # attribute the launch to the kernel rocprofv3 will name
         bn = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K))
         if bn == 8:       # the epilogue flavour is a template argument: same names as in a rocprofv3 kernel trace
-            epi = 1 if (flags & GEMM_GATE_RES) else (2 if (flags & GEMM_OUT_F32) else (4 if 0 <= gelu_from < N else 0))
+            epi = 12 if qk is not None else (1 if (flags & GEMM_GATE_RES) else (2 if (flags & GEMM_OUT_F32) else (4 if 0 <= gelu_from < N else 0)))
             ok = not (flags & (GEMM_ACT_QUICK_GELU | GEMM_ACT_GELU_ERF)) and \
                 (int(bool(flags & GEMM_GATE_RES)) + int(bool(flags & GEMM_OUT_F32)) + int(0 <= gelu_from < N)) <= 1
             if not ok:    # flavour not instantiated (CLIP activations, combinations): served by the older kernels
