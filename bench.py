@@ -274,8 +274,10 @@ def main():
     ap.add_argument("--gemm-policy", type=int, action="append", default=[],
                     help="A/B switch: pf_gemm_set_policy(value) before the model is built (e.g. -5 = no LDS-halo conv, -4 = no "
                          "tail split); repeatable.  Not for the headline line")
-    ap.add_argument("--parallelism", default="sp", choices=["sp", "replicas"],
-                    help="N > 1: sp = one video across all GPUs (default), replicas = one video per GPU")
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "guidance", "replicas"],
+                    help="N > 1: one video across all GPUs -- sp = sequence-parallel DiT (Ulysses all-to-all), guidance = the two "
+                         "ranks of N = 2 take one classifier-free-guidance branch each (no all-to-all), auto (default) = guidance "
+                         "at N = 2, sp otherwise; replicas = one video per GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -288,8 +290,10 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    use_sp = world > 1 and args.parallelism == "sp"
+    use_sp = world > 1 and args.parallelism != "replicas"
+    guidance = use_sp and world == 2 and args.parallelism in ("auto", "guidance")
     comm_used = None
+    comm_errors = []
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -309,10 +313,11 @@ def main():
             def try_comm(native):
                 """build the communicator and run every collective of the path once with known values"""
                 try:
-                    c = sp_mod.init_sequence_parallel_group(sp_group_size=world, native=native)
+                    c = sp_mod.init_sequence_parallel_group(sp_group_size=world, native=native, guidance_parallel=guidance)
                     c.selftest(device)
                     return c, True
                 except Exception as e:          # noqa: BLE001
+                    comm_errors.append(f"{'pf_comm' if native else 'torch.distributed'}: {e!r}"[:300])
                     print(f"[bench] rank {rank}: sequence-parallel self-test ({'pf_comm' if native else 'torch.distributed'}) "
                           f"failed: {e!r}", file=sys.stderr, flush=True)
                     return None, False
@@ -322,16 +327,21 @@ def main():
             if args.comm in ("auto", "native") and dist.get_backend() == "nccl":
                 comm, ok = try_comm(True)
                 if not agreed(ok):
+                    if ok:
+                        comm_errors.append("pf_comm: another rank failed its self-test")
                     comm = None
                     sp_mod._SP = None
-            if comm is None and args.comm != "native":
+            elif args.comm in ("auto", "native"):
+                # ranks sharing a GPU (test boxes): RCCL refuses duplicate devices, its init is not even attempted
+                comm_errors.append("pf_comm: not attempted (backend gloo: the ranks share GPUs, RCCL needs one GPU per rank)")
+            if comm is None:          # torch.distributed: the agreed fallback of --comm auto / native, the choice of --comm torch
                 comm, ok = try_comm(False)
                 if not agreed(ok):
                     comm = None
             if comm is None:        # all ranks agree: independent replicas instead (reported as such in the JSON line)
                 print(f"[bench] rank {rank}: no working sequence-parallel communicator; falling back to replicas",
                       file=sys.stderr, flush=True)
-                use_sp = False
+                use_sp = guidance = False
                 sp_mod._SP = None
             comm_used = comm
 
@@ -384,6 +394,7 @@ def main():
         if args.no_overlap_text:
             pipe.dit.overlap_text = False
         sp = SampledProfiler(pipe, args.profile_period)
+        pipe.phase_times = None
 
         def one_video(seed):
             if i2v:
@@ -416,6 +427,8 @@ def main():
     barrier()
     if sp is not None:
         sp.active = True
+    if pipe is not None:
+        pipe.phase_times = {}          # wall seconds of the sampling loop / the decode inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_video(i)
@@ -428,10 +441,16 @@ def main():
     else:
         assert out is None
     peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
+    ph = dict(pipe.phase_times) if (pipe is not None and pipe.phase_times) else {}
+    if pipe is not None:
+        pipe.phase_times = None
     if world > 1:
-        t = torch.tensor([dt, peak_gib], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, peak_gib, ph.get("sampling_s", 0.0), ph.get("decode_s", 0.0)], dtype=torch.float64,
+                         device=device if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, peak_gib = t[0].item(), t[1].item()
+        if ph:
+            ph = dict(sampling_s=t[2].item(), decode_s=t[3].item())
     if rank != 0:
         return
     from pyflow_hip import ops
@@ -581,13 +600,15 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True,
         # N > 1 default: ONE video over all GPUs (total work fixed) = strong scaling; the N = 1 line of the same sweep says
         # the same; `--parallelism replicas` is the weak-scaling form
-        "scaling": "strong" if (args.parallelism == "sp" and (use_sp or world == 1)) else "weak",
+        "scaling": "strong" if (args.parallelism != "replicas" and (use_sp or world == 1)) else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {model_desc} + CausalVideoVAE "
                                f"tiled(256)/chunked(1) decode (the reference's save_memory schedule; four chunk windows per launch set), {H}x{W}, temp={temp} ({frames_per_video} frames), steps {steps1}/{stepsv}, "
                                "CFG 7.0/5.0, random-init weights, synthetic prompt embeddings"
                                + (" [TINY MODEL: plumbing only]" if args.tiny_model else ""),
                    "parallelism": "single GPU" if world == 1 else (
+                       "guidance2: one video over 2 GPUs, one classifier-free-guidance branch per GPU (velocity tokens "
+                       "all-reduced per step, no all-to-all) + tile-parallel VAE decode" if guidance else
                        f"sp{world}: one video over {world} GPUs, sequence-parallel DiT (all-to-all heads<->rows over RCCL, "
                        "uneven 30-head map) + tile-parallel VAE decode" if use_sp
                        else f"{world} independent replicas (one video per GPU)")},
@@ -604,6 +625,8 @@ def main():
     # device memory the timed region needed (torch allocator high-water mark, max over ranks): the tiled decode runs four
     # tile lanes x four coalesced chunk windows, a hidden requirement of the headline number on a 288 GB part
     res["peak_mem_gib"] = round(peak_gib, 1)
+    if ph:      # where the step went (wall seconds per step, max over ranks; device idle at both boundaries)
+        res["phases"] = {k: round(v / args.steps, 3) for k, v in ph.items()}
     if world > 1:
         backend = torch.distributed.get_backend()
         res["launcher"] = "bench.py self-launch" if os.environ.get("PF_BENCH_LAUNCHER") == "self" else "external (torchrun)"
@@ -611,6 +634,9 @@ def main():
         res["communicator"] = ("pf_comm (C-ABI RCCL communicator)" if getattr(comm_used, "backend", "") == "pf_comm" else
                                f"torch.distributed ({backend}" + (" = RCCL)" if backend == "nccl" else
                                "; ranks share GPUs, transport through the host: PLUMBING ONLY, not a measurement)"))
+        res["requested_parallelism"] = args.parallelism
+        if comm_errors:      # why a communicator was not used (rank 0's view; every rank agreed on the outcome)
+            res["communicator_fallback_reason"] = comm_errors
     if i2v:
         res["metric"] = "video frames/sec for 768p image-to-video sampling (config C4, not the headline metric)"
         res["config"]["workload"] = (f"{args.workload}: {model_desc} generate_i2v + CausalVideoVAE "

@@ -283,16 +283,25 @@ static bool g_narrow_enabled = true;         // pf_gemm_set_policy(-3) / (3): ne
 static bool g_halo_enabled = true;           // pf_gemm_set_policy(-5) / (5): never / again the LDS-halo direct conv (N = 128 layers)
 static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
-static bool use_gemm8p(int M, int batch, int N, int K) {
-    if (g_gemm8p_mode < 0 || N % 8 || K % 64) return false;
-    if (g_gemm8p_mode > 0) return true;
-    if (!g_gemm8p_auto || gemm256_force() != 0) return false;          // an explicit tile-width policy addresses the older kernels
+// 1 = a launch of >= 192 tiles (whole rounds + tail), 2 = a MID-SIZE launch (32 .. 128 tiles, e.g. a sequence-parallel rank's
+// N = 1920 projections at P = 4 / 8: flux_block.py:868-872, 914-942 on L / P rows) that runs the persistent kernel on the
+// WHOLE chip by splitting every tile's K range over 256 / T workgroups (the tail-split path with no full round in front:
+// gemm8p.hip tail_plan) -- only with caller scratch, only when the split pays by that plan; 0 = not a gemm8p problem
+int pf_gemm8p_mid_split(int tiles, int nk);                                // gemm8p.hip: parts per tile (1 = no gain)
+static int use_gemm8p_kind(int M, int batch, int N, int K) {
+    if (g_gemm8p_mode < 0 || N % 8 || K % 64) return 0;
+    if (g_gemm8p_mode > 0) return 1;
+    if (!g_gemm8p_auto || gemm256_force() != 0) return 0;          // an explicit tile-width policy addresses the older kernels
     // automatic: problems of at least 3/4 of a round of 256 x 256 tiles whose N tail wastes < 7 % of the columns
     // (a sequence-parallel rank at P = 8 runs the 7d-wide projections with 16 x 53 tiles and the 4d-wide with 16 x 30)
     const long long tiles = (long long)((M + 255) / 256) * batch * ((N + 255) / 256);
     const int n256 = (N + 255) / 256 * 256;
-    return tiles >= 192 && (n256 - N) * 100 < 7 * N;
+    if ((n256 - N) * 100 >= 7 * N) return 0;
+    if (tiles >= 192) return 1;
+    if (tiles >= 32 && tiles <= 128 && M >= 192 && pf_gemm8p_mid_split((int)tiles, K / 64) > 1) return 2;
+    return 0;
 }
+static bool use_gemm8p(int M, int batch, int N, int K) { return use_gemm8p_kind(M, batch, N, K) != 0; }
 extern "C" int pf_gemm_set_policy(int force) {
     if (force == 8 || force == -8) { g_gemm8p_mode = force > 0 ? 1 : -1; g_gemm256_force = 0; return 0; }
     if (force == 2 || force == -2) { g_splitk_enabled = force > 0; return 0; }
@@ -360,7 +369,10 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
                                d->qk_rope + (long long)d->qk_row0 * 64, d->batch, d->M, 0, d->qk_d / 64, d->qk_eps,
                                d->qk_q_scale, 64, stream);
     };
-    const bool g8 = use_gemm8p(d->M, d->batch, d->N, d->K) && pf_gemm8p_supports(a, false);
+    // (a mid-size problem takes the persistent kernel only with its scratch: without it the older kernels fill the chip better)
+    const int kind8 = use_gemm8p_kind(d->M, d->batch, d->N, d->K);
+    const bool ws8 = !qk && d->workspace && d->workspace_bytes >= pf_gemm8p_workspace_bytes();
+    const bool g8 = (kind8 == 1 || (kind8 == 2 && ws8)) && pf_gemm8p_supports(a, false);
     if (!g8 && !bn256 && d->N % BN != 0)
         return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (g8) {

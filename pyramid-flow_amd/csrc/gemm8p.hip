@@ -36,6 +36,8 @@
 
 using namespace pfgemm;
 
+int pf_gemm8p_mid_split(int tiles, int nk);      // parts per tile of a launch of < one round of tiles (defined at the end)
+
 namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -712,7 +714,11 @@ int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
     }
     Args a = a_in;
     const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
-    const int grid = tiles < g_num_cu ? tiles : g_num_cu;
+    // fewer tiles than CUs: with scratch the whole chip is launched anyway and the spare workgroups take K ranges of the
+    // tiles (tail_plan with no full round: every tile is a tail tile), when that plan splits at all
+    const bool can_split = !CONV && g_tail_split && ws && ws_bytes >= (long long)g_num_cu * (256 << 10) && (g_num_cu & 7) == 0;
+    const bool mid = can_split && tiles < g_num_cu && pf_gemm8p_mid_split(tiles, a.K / BK) > 1;
+    const int grid = (tiles < g_num_cu && !mid) ? tiles : g_num_cu;
     // tail split: one 256-KiB slot of caller scratch per workgroup; the second launch covers the XCD with the most tail tiles
     a.part = nullptr;
     a.ksplit = grid;
@@ -744,6 +750,16 @@ bool pf_gemm8p_supports(const Args& a, bool conv) {
     if (conv && (f32 || act || res)) return false;      // conv + shortcut add: the instantiation spills (kept on gemm256)
     if (act && (a.gelu_from & 31)) return false;        // the activation is decided per 32-column half of a wave tile
     return true;
+}
+
+// parts per tile when a launch of `tiles` (< one round) tiles is spread over the whole chip by splitting K (the plan of the
+// XCD with the most tiles); 1 = the split does not pay / is not possible
+int pf_gemm8p_mid_split(int tiles, int nk) {
+    if (!g_tail_split) return 1;
+    const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+    if (tiles >= ncu || (ncu & 7)) return 1;
+    const int clen = (tiles + 7) >> 3;
+    return tail_plan(clen, ncu >> 3, nk, g_tail_ov).sp;
 }
 
 void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }

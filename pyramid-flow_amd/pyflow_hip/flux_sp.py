@@ -48,6 +48,7 @@ class FluxEngineSP(FluxEngine):
         self.comm = comm if comm is not None else LocalComm()
         self._layouts = {}
         self.launch_mode = "list"          # "list": record + replay when the communicator allows it; "eager": never
+        self.split_small = True            # a rank's small image GEMMs (128 x 128 kernel, < 128 workgroups) split K through scratch
 
     def layout(self, plan):
         key = (plan.L, plan.Lt)
@@ -188,7 +189,7 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 6 * d, mb + 7 * d)
             if n_img:
                 ops.gemm(xn, blk["kvq_img"][0], big, n_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, tail_workspace=ws_img)
+                         strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, tail_workspace=ws_img, split_small=self.split_small)
             if n_txt:
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
                          strideA=Ld, strideC=L3, workspace=ws_txt)
@@ -199,7 +200,7 @@ class FluxEngineSP(FluxEngine):
             if n_act > 0:
                 ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small)
             if n_txt and not pre_only:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
@@ -209,11 +210,11 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
             if n_act > 0:
                 ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
-                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d, tail_workspace=ws_img)
+                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d, tail_workspace=ws_img, split_small=self.split_small)
                 ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                          res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + i0 * 4 * d, c_off=i0 * d,
-                         r_off=i0 * d, tail_workspace=ws_img)
+                         r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small)
             if n_txt and not pre_only:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
@@ -234,13 +235,13 @@ class FluxEngineSP(FluxEngine):
             # K|V|Q first, then the MLP branch (proj_mlp + GELU, flux_block.py:921-922) while the exchanges fly
             if nloc:
                 ops.gemm(xn, blk["kvqm"][0], big, nloc, 3 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, tail_workspace=ws_img)
+                         strideC=L7, tail_workspace=ws_img, split_small=self.split_small)
 
             def mlp_cols(c0, nc, blk=blk, i0=i0, n_act=n_act):
                 if n_act > 0 and nc > 0:
                     ops.gemm(xn, blk["kvqm"][0], big, n_act, nc, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B,
                              strideA=Ld, strideC=L7, gelu_from=0, a_off=i0 * d, w_off=(3 * d + c0) * d,
-                             c_off=i0 * 7 * d + 3 * d + c0, bias_off=3 * d + c0, tail_workspace=ws_img)
+                             c_off=i0 * 7 * d + 3 * d + c0, bias_off=3 * d + c0, tail_workspace=ws_img, split_small=self.split_small)
             norms = (blk["norm_q"], blk["norm_k"], None, None)
             attend(7 * d, norms, overlap=lambda: mlp_cols(0, n1), q_row_begin=r_cur if last else 0)
             h2 = self._exchange_out_start(lay, obuf, B, recv2)
@@ -249,7 +250,7 @@ class FluxEngineSP(FluxEngine):
             if n_act > 0:
                 ops.gemm(big, blk["out"][0], hidden, n_act, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 7 * d + 2 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img)
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 7 * d + 2 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small)
         if debug is not None:
             debug["hidden_final_local"] = hidden[:B * nloc * d].view(B, nloc, d).clone()
 
@@ -271,7 +272,7 @@ class FluxEngineSP(FluxEngine):
         n_mod = plan.B * self.w.n_mod
         for _ in range(2):
             ms = self._buf("mod_fixed", n_mod, torch.float32)
-            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm))
+            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm), self.split_small)
             ent = getattr(plan, "_sp_list", None)
             if ent is not None and ent[0] == key:
                 break

@@ -46,7 +46,7 @@ RECORDER = None      # a cmdlist.CommandList while a launch list is being record
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
-         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None, tail_workspace=None, qk=None):
+         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None, tail_workspace=None, qk=None, split_small=False):
     """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res.  workspace: fp32 scratch tensor that lets
     a skinny problem split its K range and a large one split its tail tiles (pf_gemm_desc.workspace); must not be
     shared by overlapping launches.  tail_workspace: the same, but handed over only to problems that run the persistent
@@ -66,9 +66,12 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr = M, N, K, lda, ldw, ldc, ldr
     d.strideA, d.strideC, d.strideR = strideA, strideC, strideR
     d.gate_stride, d.batch, d.gelu_from, d.flags = gate_stride, batch, gelu_from, flags
-    if workspace is None and tail_workspace is not None and \
-            lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K)) == 8:
-        workspace = tail_workspace
+    if workspace is None and tail_workspace is not None:
+        which = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K))
+        # split_small (the sequence-parallel engine's image rows: a rank's few rows leave the 128 x 128 kernel with < 128
+        # workgroups, each a long chain of K-tiles): those problems may split K through the same scratch
+        if which == 8 or (split_small and which == 0):
+            workspace = tail_workspace
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     if qk is not None:

@@ -13,6 +13,7 @@ Host loop = the reference's (autoregressive units x pyramid stages x Euler steps
 """
 import json
 import math
+import time
 import os
 
 import numpy as np
@@ -66,7 +67,10 @@ class PyramidDiTForVideoGeneration:
         # like the reference (flux_block.py:734-743), the sequence-parallel form is chosen at construction time:
         # init_sequence_parallel_group() must have run before the model is built
         self.sp = sp_mod.get_sequence_parallel_comm() if sp_mod.is_sequence_parallel_initialized() else None
-        if self.sp is not None and self.sp.world > 1:
+        if self.sp is not None and self.sp.world == 2 and sp_mod.is_guidance_parallel():
+            from .flux_cfg import FluxEngineCFG          # two ranks: one branch of the guidance pair each, no all-to-all
+            self.dit = FluxEngineCFG(dit_state_dict, dit_config, device, comm=self.sp)
+        elif self.sp is not None and self.sp.world > 1:
             from .flux_sp import FluxEngineSP
             self.dit = FluxEngineSP(dit_state_dict, dit_config, device, comm=self.sp)
         else:
@@ -328,6 +332,10 @@ class PyramidDiTForVideoGeneration:
             x = y
         num_units = 1 + (temp - 1) // self.frame_per_unit
         generated = [[] for _ in range(nb)]
+        phases = getattr(self, "phase_times", None)      # bench.py: a dict that accumulates wall seconds per phase
+        if phases is not None:
+            torch.cuda.synchronize()
+            t_ph = time.perf_counter()
         for unit_index in range(num_units):
             if callback:
                 callback(unit_index, num_units)
@@ -345,10 +353,18 @@ class PyramidDiTForVideoGeneration:
             for b in range(nb):
                 generated[b].append(outs[b][-1])
         gen = torch.stack([torch.cat(g_, dim=1) for g_ in generated])                # [B,C,T,h,w] fp32
+        if phases is not None:
+            torch.cuda.synchronize()
+            phases["sampling_s"] = phases.get("sampling_s", 0.0) + time.perf_counter() - t_ph
+            t_ph = time.perf_counter()
         if output_type == "latent":
             return gen.to(pe.dtype) if self._round else gen
-        return self.decode_latent(gen, save_memory=save_memory, inference_multigpu=inference_multigpu,
-                                  output_type=output_type)
+        out = self.decode_latent(gen, save_memory=save_memory, inference_multigpu=inference_multigpu,
+                                 output_type=output_type)
+        if phases is not None:
+            torch.cuda.synchronize()
+            phases["decode_s"] = phases.get("decode_s", 0.0) + time.perf_counter() - t_ph
+        return out
 
     @torch.no_grad()
     def decode_latent(self, latents, save_memory=True, inference_multigpu=False, output_type="pil"):

@@ -263,15 +263,19 @@ class SPComm:
 # ---- reference-named helpers (trainer_misc/sp_utils.py) ---------------------------------------------------------
 _SP = None
 _SP_PROC_NUM = None
+_GUIDANCE_PARALLEL = False
 
 
-def init_sequence_parallel_group(args=None, sp_group_size=None, native=False):
+def init_sequence_parallel_group(args=None, sp_group_size=None, native=False, guidance_parallel=False):
     """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world) over the
     first `args.sp_proc_num` processes (-1 / absent = all).  A process outside every group stays un-initialised.
     native=True (whole-world group only): the collectives go through the C-ABI communicator (pf_comm_*, RCCL driven
     directly on its own HIP stream) instead of torch.distributed; torch.distributed is used once, to ship the id."""
-    global _SP, _SP_PROC_NUM
+    global _SP, _SP_PROC_NUM, _GUIDANCE_PARALLEL
     world = dist.get_world_size()
+    # guidance_parallel (a world of two only; not a reference option): the two ranks split the classifier-free-guidance pair
+    # instead of the sequence (pyflow_hip/flux_cfg.py) -- the group and its collectives are the same, the engine differs
+    _GUIDANCE_PARALLEL = bool(guidance_parallel) and world == 2
     if native:
         from .comm_native import NativeComm, exchange_unique_id
         rank = dist.get_rank()
@@ -299,6 +303,10 @@ def init_sequence_parallel_group(args=None, sp_group_size=None, native=False):
 
 def is_sequence_parallel_initialized():
     return _SP is not None
+
+
+def is_guidance_parallel():
+    return _SP is not None and _GUIDANCE_PARALLEL
 
 
 def get_sequence_parallel_comm():
@@ -331,5 +339,5 @@ def get_sequence_parallel_proc_num():
 
 def reset_sequence_parallel():
     """test hook: forget the group (the reference has no teardown; a process normally initialises once)"""
-    global _SP, _SP_PROC_NUM
-    _SP, _SP_PROC_NUM = None, None
+    global _SP, _SP_PROC_NUM, _GUIDANCE_PARALLEL
+    _SP, _SP_PROC_NUM, _GUIDANCE_PARALLEL = None, None, False

@@ -24,12 +24,25 @@ def _run(extra):
     return json.loads(lines[0])
 
 
-def test_self_launch_sequence_parallel_two_ranks():
+def test_self_launch_default_two_ranks_is_guidance_parallel():
+    """N = 2 default: one classifier-free-guidance branch per rank (pyflow_hip/flux_cfg.py), no all-to-all"""
     r = _run([])
     assert r["n_gpus"] == 2 and r["launcher"] == "bench.py self-launch" and r["scaling"] == "strong"
-    assert r["config"]["parallelism"].startswith("sp2") and r["value"] > 0 and r["peak_mem_gib"] > 0
+    assert r["config"]["parallelism"].startswith("guidance2") and r["value"] > 0 and r["peak_mem_gib"] > 0
     assert r["metric"].startswith("PLUMBING RUN") and "TINY MODEL" in r["config"]["workload"]
-    assert "communicator" in r and "rccl_ranks" in r
+    assert "communicator" in r and "rccl_ranks" in r and r["requested_parallelism"] == "auto"
+    assert r["phases"]["sampling_s"] > 0 and r["phases"]["decode_s"] > 0          # per-phase wall time (max over ranks)
+
+
+def test_self_launch_sequence_parallel_two_ranks_and_native_communicator_dry_run():
+    """--parallelism sp: the Ulysses engine on two ranks.  --comm native on a box whose ranks share ONE GPU cannot have the
+    C-ABI RCCL communicator (duplicate device): every rank takes the agreed torch.distributed fallback and the line still
+    comes out complete, naming the communicator that ran and why the requested one did not."""
+    r = _run(["--parallelism", "sp", "--comm", "native"])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"].startswith("sp2") and r["value"] > 0
+    assert r["communicator"].startswith("torch.distributed") and r["rccl_ranks"] == 0
+    assert any("pf_comm" in e for e in r["communicator_fallback_reason"])
+    assert r["phases"]["sampling_s"] > 0
 
 
 def test_self_launch_replicas_two_ranks():

@@ -281,3 +281,40 @@ def test_gemm8p_tail_split_policy_switch(ws64):
     assert torch.equal(C0, C1) and not torch.equal(C0, C2)
     assert rel_l2(C2, C0) < 1e-6
     assert ops.L.load().pf_gemm_workspace_bytes(M, 1, N, K) == 64 << 20
+
+
+@pytest.mark.parametrize("M,B,N,K", [(1936, 2, 1920, 7680), (1936, 2, 1920, 9600), (946, 2, 1920, 9600), (946, 2, 1920, 1920),
+                                     (496, 2, 1920, 9600), (1210, 1, 1920, 7680)])
+def test_gemm8p_mid_size_whole_launch_k_split(ws64, M, B, N, K):
+    """a sequence-parallel rank's N = 1920 projections (P = 4 / 8: L / P rows, 32 .. 128 tiles of 256 x 256): with scratch the
+    persistent kernel is launched on the whole chip and every tile's K range is split over 256 / T workgroups (tail_plan with
+    no full round); without scratch the same problem runs the older kernels.  Same result up to fp32 summation order;
+    residual + gate and GELU flavours through the second launch."""
+    from pyflow_hip import ops
+    so = ops.L.load()
+    assert so.pf_gemm_which(M, B, N, K) == 8 and so.pf_gemm_workspace_bytes(M, B, N, K) > 0
+    L = M + 5
+    A = _mk((B, L, K), 11).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 12, 0.02).to(torch.bfloat16).to(DEV)
+    bias = _mk((N,), 13).to(DEV)
+    hid = _mk((B, L, N), 14).to(torch.bfloat16).to(DEV)
+    gate = _mk((B, N), 15).to(DEV)
+    outs = []
+    for ws in (ws64, None, ws64):
+        h = hid.clone()
+        ops.gemm(A, W, h, M, N, K, K, K, N, bias=bias, res=h, gate=gate, ldr=N, batch=B, strideA=L * K, strideC=L * N,
+                 strideR=L * N, gate_stride=N, flags=ops.GEMM_GATE_RES, workspace=ws)
+        outs.append(h)
+    ref = hid[:, :M].float() + gate[:, None] * (A[:, :M].float() @ W.float().T + bias)
+    for h in outs:
+        assert rel_l2(h[:, :M].float(), ref) < 5e-3
+        assert torch.equal(h[:, M:], hid[:, M:])                          # rows beyond M untouched
+    assert torch.equal(outs[0], outs[2])                                  # repeatable (parts added in part order)
+    assert rel_l2(outs[0].float(), outs[1].float()) < 2e-3
+    # GELU flavour + plain bf16 output through the same path
+    C = torch.zeros(B, L, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A, W, C, M, N, K, K, K, N, bias=bias, batch=B, strideA=L * K, strideC=L * N, gelu_from=N // 2 // 32 * 32, workspace=ws64)
+    r2 = A[:, :M].float() @ W.float().T + bias
+    g0 = N // 2 // 32 * 32
+    r2[..., g0:] = F.gelu(r2[..., g0:], approximate="tanh")
+    assert rel_l2(C[:, :M].float(), r2) < 5e-3 and C[:, M:].abs().max() == 0

@@ -122,6 +122,13 @@ def test_sp_generate_and_tile_parallel_decode(tmp_path, world):
     _launch(world, "sp_pipeline_worker.py", [], tmp_path)
 
 
+def test_guidance_parallel_generate_two_ranks(tmp_path):
+    """two ranks, one classifier-free-guidance branch each (pyflow_hip/flux_cfg.py; pipeline.py:747-776 evaluates the pair as
+    one batch of 2): whole generate() + tile-parallel decode against the single-process pipeline (latents <= 2e-3: only the
+    GEMMs' fp32 summation order can differ)"""
+    _launch(2, "sp_pipeline_worker.py", ["cfg"], tmp_path)
+
+
 @pytest.mark.parametrize("world,T", [(2, 5), (3, 7)])
 def test_vae_context_parallel(tmp_path, world, T):
     """temporal context-parallel VAE decode (halo exchange per causal conv, uneven frame ranges) == single process"""
