@@ -40,6 +40,10 @@ struct AArgs {
     float sc;   // softmax scale * log2(e)
     unsigned* dbg;   // lab builds only (cycle stamps of attn64_kernel<.., 2>); nullptr in the library
     int* wgflags;    // attn64 FAST / FIXUP pair: one int per wave (4 per workgroup), caller scratch
+    // KV split of launches with too few workgroups for the chip (attention_w64.h SPLIT / COMBINE; caller scratch):
+    int nsplit, kv_chunk;       // parts per query tile, 64-key tiles per part
+    float* parts;               // [unit][wave][18 KiB]: unnormalised fp32 O and row sums of one part, lane-linear
+    int* part_flags;            // [unit][wave]: the part produced a non-finite sum
 };
 
 template <bool PRE, int ILP, int OCC>
@@ -338,14 +342,25 @@ __global__ __launch_bounds__(256) void vtrans_kernel(const bf16_t* V, bf16_t* Vt
 
 int pf_set_err(const char* m);
 
-// one int per wave of the 256-row kernel's grid (4 per workgroup)
+// Scratch of the 64-rows-per-wave pair: one int per wave of its grid (4 per workgroup) + the KV-split region (launches
+// with too few workgroups for the chip: attention_w64.h SPLIT / COMBINE): at most SPLIT_UNITS (query tile, part) units of
+// 4 waves x (18 KiB of parked sums + one flag).
+constexpr int SPLIT_UNITS = 1280;                 // 640 workgroups x 2 parts, or 256 x 4
+constexpr long long PART_BYTES = 18 * 1024;       // per wave
+static long long w64_flag_bytes(int B, int H, int L) { return (((long long)((L + 255) / 256) * H * B * 4 * (long long)sizeof(int)) + 255) & ~255ll; }
 extern "C" long long pf_attention_workspace_bytes(int B, int H, int L) {
     if (B <= 0 || H <= 0 || L <= 0) return 0;
-    return (long long)((L + 255) / 256) * H * B * 4 * (long long)sizeof(int);
+    return w64_flag_bytes(B, H, L) + (long long)SPLIT_UNITS * 4 * (PART_BYTES + 16);
+}
+// parts per query tile for a launch of `nwg` 256-row workgroups over `ntiles` key tiles (1 = no split): launches of at most
+// 1.25 rounds of the chip's 512 workgroup slots are cut along the keys into chunks of at least 8 tiles
+static int w64_split(long long nwg, int ntiles) {
+    if (nwg >= 640 || ntiles < 16) return 1;
+    int s_ = nwg >= 256 ? 2 : 4;
+    while (s_ > 1 && (ntiles + s_ - 1) / s_ < 8) s_ >>= 1;
+    return s_;
 }
 
-// the 64-rows-per-wave pair needs caller scratch, pre-scaled q, 16-byte aligned output rows and at least two 256-row
-// workgroups per CU (below that the 128-row kernel keeps more of the chip busy)
 // ... and an output that either does not touch Q at all or IS Q (the in-place form of the DiT: same address, leading
 // dimension, batch stride and packed heads -- then every wave overwrites exactly the 64 Q rows it alone reads, and the
 // fast pass leaves the rows of a flagged wave unwritten for the fix-up launch; attention_w64.h).  Any other overlap of
@@ -365,11 +380,19 @@ static bool use_w64(const pf_attn_desc* d) {
     const int nqt = (d->L + QB - 1) / QB;
     const int qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
     const long long grid64 = (long long)((nqt + 1) / 2 - qt0 / 2) * d->H * d->B;
-    return d->workspace_bytes >= pf_attention_workspace_bytes(d->B, d->H, d->L) && grid64 >= 512 && (d->ldo % 8) == 0 &&
+    // at least one round of the chip after the KV split (4 parts from 128 workgroups up)
+    const bool enough = grid64 * w64_split(grid64, (d->L + KB - 1) / KB) >= 512;
+    return d->workspace_bytes >= pf_attention_workspace_bytes(d->B, d->H, d->L) && enough && (d->ldo % 8) == 0 &&
            (d->strideO % 8) == 0 && ((uintptr_t)d->O % 16) == 0 && ((uintptr_t)d->workspace % 4) == 0;
 }
 
-extern "C" int pf_attention_which(const pf_attn_desc* d) { return (d && use_w64(d)) ? 64 : 32; }
+// 32 = the 128-row kernel, 64 = the 64-rows-per-wave pair, 64 + parts = the pair with its key range split into `parts`
+extern "C" int pf_attention_which(const pf_attn_desc* d) {
+    if (!d || !use_w64(d)) return 32;
+    const int nqt = (d->L + QB - 1) / QB, qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
+    const int sp = w64_split((long long)((nqt + 1) / 2 - qt0 / 2) * d->H * d->B, (d->L + KB - 1) / KB);
+    return sp > 1 ? 64 + sp : 64;
+}
 
 extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     if (!d || !d->Q || !d->K || !d->Vt || !d->O) return pf_set_err("pf_attention_bf16: null operand");
@@ -395,6 +418,27 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
         constexpr int SM64 = 2 * ABUF + 4 * 64 * HD * 2;
         const int grid64 = ((a.nqt + 1) / 2 - a.qt0 / 2) * a.H * a.B;
         a.wgflags = (int*)d->workspace;
+        const int ntl = (a.L + KB - 1) / KB;
+        const int sp = w64_split(grid64, ntl);
+        if (sp > 1) {
+            // too few workgroups for the chip: SPLIT (fast pass over `sp` key ranges per query tile, sums parked) -> COMBINE
+            // (adds the parts, range check, store or flag) -> FIXUP (flagged workgroups, as always)
+            char* reg = (char*)d->workspace + w64_flag_bytes(a.B, a.H, a.L);
+            a.nsplit = sp;
+            a.kv_chunk = (ntl + sp - 1) / sp;
+            a.part_flags = (int*)reg;
+            a.parts = (float*)(reg + (long long)SPLIT_UNITS * 4 * 16);
+            if ((long long)grid64 * sp > SPLIT_UNITS) return pf_set_err("pf_attention_bf16: split units exceed the scratch");
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33 | 64>), SM64);
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33 | 128>), SM64);
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
+            hipLaunchKernelGGL((attn64_kernel<2, 33 | 64>), dim3(grid64 * sp), dim3(256), SM64, stream, a);
+            hipLaunchKernelGGL((attn64_kernel<2, 33 | 128>), dim3(grid64), dim3(256), SM64, stream, a);
+            hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
+            hipError_t es = hipGetLastError();
+            if (es != hipSuccess) return pf_set_err(hipGetErrorString(es));
+            return 0;
+        }
         // FAST | MMSUM (33): row sums on the matrix pipe, +1.5 % (L = 15 488) ... +3 % (L = 3 008) over the v_add_f32 sums
         // (mode 1) in the same-box A/B of profiles/r04_attention_rowsum_variants.log; the v_dot2c / v_pk_add forms lose 2-3 %
         PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33>), SM64);

@@ -49,6 +49,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     //       per 32 rows x 64 keys of a kernel that is bound by vector issue); the sums accumulate in 4 registers per block and
     //       are read out once, in the epilogue; the denominator then sums exactly the rounded values the numerator multiplies.
     constexpr bool MMSUM = (MODE & 32) != 0;
+    // bit 6 SPLIT / bit 7 COMBINE (both forms of FAST | MMSUM): a launch with fewer workgroups than ~1.25 rounds of the chip
+    //       (a sequence-parallel rank's few heads: 4 heads x 2 x 61 query tiles = 488 workgroups whose heaviest sees 242 key
+    //       tiles, the mean 143) is cut along the KEYS: workgroup (query tile, part) runs key tiles [part * kv_chunk, ...) and
+    //       parks its unnormalised fp32 O and row sums (no running maximum in the fast pass: parts simply ADD); the COMBINE
+    //       launch (one workgroup per query tile, no key loop) adds the parts in part order, applies the fast pass's range
+    //       check to the total and stores -- or flags the wave for the FIXUP launch, exactly like the unsplit pair.
+    constexpr bool SPLIT = (MODE & 64) != 0, COMBINE = (MODE & 128) != 0;
+    static_assert(!(SPLIT || COMBINE) || (FAST && MMSUM && !(SPLIT && COMBINE) && NW == 4), "SPLIT / COMBINE are forms of the fast pass");
+    constexpr int PART_FLOATS = 18 * 256;          // per wave: 16 KiB of O (64 registers x 64 lanes) + 2 KiB of row sums
     static_assert(!MMSUM || (FAST && !DOTSUM && !PKSUM), "MMSUM is a form of the FAST pass");
     typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
     using ps_t = typename std::conditional<PKSUM, f32x2_t_, float>::type;
@@ -75,10 +84,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nq2 = (p.nqt + NT - 1) / NT, qt0 = p.qt0 / NT;
     const int nq_run = nq2 - qt0;
-    const int nwg = nq_run * p.H * p.B;
+    const int S = SPLIT ? p.nsplit : 1;
+    const int nwg = nq_run * S * p.H * p.B;
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int bh = t / nq_run;
-    const int qt = nq2 - 1 - (t - bh * nq_run);      // heaviest (latest) q tiles first
+    const int bh = t / (nq_run * S);
+    const int rem_ = t - bh * (nq_run * S);
+    const int qrank = rem_ / S, part = rem_ - qrank * S;
+    const int qt = nq2 - 1 - qrank;                  // heaviest (latest) q tiles first
+    const int unit0 = (bh * nq_run + qrank) * ((SPLIT || COMBINE) ? p.nsplit : 1);      // first part slot of this query tile
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qt * QB2;
     const int frow = lane & 31, hi = lane >> 5, swz = (lane >> 1) & 7;
@@ -112,6 +125,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     for (int i = 0; i < NT; ++i)
         if (NT * qt + i < p.nqt) kv_end = max(kv_end, p.tile_kv_end[b * p.nqt + NT * qt + i]);
     const int ntiles = (kv_end + KB - 1) / KB;
+    // the key tiles [jt0, jt1) this workgroup walks: all of them; one part of them (SPLIT); none (COMBINE adds parked parts)
+    int jt0 = 0, jt1 = ntiles;
+    if (SPLIT) {
+        jt0 = part * p.kv_chunk;
+        jt1 = min(ntiles, jt0 + p.kv_chunk);
+        if (jt0 >= jt1) return;                       // this query tile has fewer parts (workgroup-uniform, before any barrier)
+    }
+    if (COMBINE) jt1 = 0;
     const int wmax_s = __builtin_amdgcn_readfirstlane(wmax), wmin_s = __builtin_amdgcn_readfirstlane(wmin);
     // tiles this wave computes: the text tiles and every image tile below the largest visibility bound of its 64 rows
     // (bounds are monotone in the key index, so the active tiles are a prefix; the rest only keeps the barrier / DMA going)
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     };
     // the wave's own 64 query rows -> LDS, same 128-byte-row image and chunk swizzle as a K tile (piece k = rows 8k..8k+7:
     // lane -> row 8k + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ ((row >> 1) & 7)); only this wave reads them
-    {
+    if (!COMBINE) {
         const char* qbase = (const char*)(p.Q + (long long)b * p.sQ + h * p.hs_qk);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -298,13 +319,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     };
 
     // ---- prologue: Q rows and tiles 0, 1 in flight; tile 0 and Q landed; first K / Q fragments requested
-    if (ntiles > 0) {
+    if (jt1 > jt0) {
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) { issue_k(0, 0, j); issue_v(0, 0, j); }
+        for (int j = 0; j < PJ; ++j) { issue_k(jt0, jt0 & 1, j); issue_v(jt0, jt0 & 1, j); }
     }
-    if (ntiles > 1) {
+    if (jt1 > jt0 + 1) {
 #pragma unroll
-        for (int j = 0; j < PJ; ++j) { issue_k(1, 1, j); issue_v(1, 1, j); }
+        for (int j = 0; j < PJ; ++j) { issue_k(jt0 + 1, (jt0 + 1) & 1, j); issue_v(jt0 + 1, (jt0 + 1) & 1, j); }
         if (PJ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     }
     __builtin_amdgcn_s_barrier();
     bf16x8_t qfa[4], qfb[4];
-    if (my_nt > 0) { read_k(0); read_q(0, qfa); }
+    if (my_nt > jt0) { read_k(jt0 & 1); read_q(0, qfa); }
 
     unsigned ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int k) {
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         }
         stamp(3);
         // ---- tile boundary: tile jt+1 has landed for everyone, every wave is done reading tile jt
-        if (jt + 1 < ntiles) {
+        if (jt + 1 < jt1) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             stamp(4);
@@ -445,7 +466,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         }
         PF_SEG();
         stamp(5);
-        const bool more = jt + 2 < ntiles;
+        const bool more = jt + 2 < jt1;
         if (active && FAST) {
             // S3 (FAST): PV(B) with the last two exponential slots of block B and the DMA pieces of tile jt+2 between its pairs
 #pragma unroll
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         }
     };
 
-    for (int jt = 0; jt < ntiles; ++jt) {
+    for (int jt = jt0; jt < jt1; ++jt) {
         const int j0 = jt * KB;
         const bool masked = (j0 < p.Lt) || (j0 + KB > wmin_s);      // scalar (wave-uniform)
         tile(masked, jt);
@@ -509,6 +530,51 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         for (int i = 0; i < 8; ++i) d_[i] = ph[i];
     }
 #undef PF_SEG
+
+    // ---- SPLIT: park this part's unnormalised sums (lane-linear 16-byte pieces, 1 KiB per wave-instruction) and whether
+    //      they are finite; the COMBINE launch owns the range check of the total, the flags and the store
+    if constexpr (SPLIT) {
+        if (!wave_runs) return;
+        float* dst = p.parts + ((long long)(unit0 + part) * NW + wid) * PART_FLOATS + lane * 4;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *(f32x4_t*)(dst + ((x * 2 + i) * 4 + q4) * 256) =
+                        (f32x4_t){o[x][i][4 * q4], o[x][i][4 * q4 + 1], o[x][i][4 * q4 + 2], o[x][i][4 * q4 + 3]};
+        *(f32x4_t*)(dst + 16 * 256) = lacc[0];
+        *(f32x4_t*)(dst + 17 * 256) = lacc[1];
+        bool nonfinite = false;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) nonfinite = nonfinite || !(row_sum(x) < 1e30f);
+        const int any_nf = __builtin_amdgcn_ballot_w64(nonfinite) != 0 ? 1 : 0;
+        if (lane == 0) p.part_flags[(unit0 + part) * NW + wid] = any_nf;
+        return;
+    }
+    bool part_bad = false;
+    if constexpr (COMBINE) {
+        if (wave_runs) {
+            const int nparts = min(p.nsplit, (ntiles + p.kv_chunk - 1) / p.kv_chunk);
+            for (int pt = 0; pt < nparts; ++pt) {                 // in part order: bitwise repeatable
+                const float* src = p.parts + ((long long)(unit0 + pt) * NW + wid) * PART_FLOATS + lane * 4;
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4_t v4 = *(const f32x4_t*)(src + ((x * 2 + i) * 4 + q4) * 256);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[x][i][4 * q4 + e] += v4[e];
+                        }
+                lacc[0] += *(const f32x4_t*)(src + 16 * 256);
+                lacc[1] += *(const f32x4_t*)(src + 17 * 256);
+                part_bad = part_bad || p.part_flags[(unit0 + pt) * NW + wid] != 0;
+            }
+        }
+    }
 
     // ---- FAST: did every valid row end with a usable denominator?  (inf / NaN: a score beyond the fp32 range of exp2; ~0: every
     //      score far below zero.)  One flag per wave; the FIXUP launch recomputes flagged workgroups with the running maximum.
@@ -522,6 +588,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
             const bool valid = qrow < p.L && qrow >= row_lo;
             bad = bad || (valid && !(lx > 1e-30f && lx < 1e30f));
         }
+        bad = bad || part_bad;
         const int any_bad = (wave_runs && __builtin_amdgcn_ballot_w64(bad) != 0) ? 1 : 0;
         if (lane == 0) p.wgflags[NW * blockIdx.x + wid] = any_bad;
         store = store && !any_bad;          // a flagged wave leaves its rows (== its Q rows when O aliases Q) to the fix-up launch

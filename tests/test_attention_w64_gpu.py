@@ -205,3 +205,101 @@ def test_pair_is_not_chosen_for_a_partial_overlap_of_output_and_q():
     assert lib.load().pf_attention_which(C.byref(d)) == 32
     d.O, d.ldo, d.strideO = d.Q, D, L * D                          # same start, other leading dimension
     assert lib.load().pf_attention_which(C.byref(d)) == 32
+
+
+# ---- KV split: launches with too few workgroups for the chip (a sequence-parallel rank's few heads) ------------------------
+def _few_heads_case(Hh, clips, case, seed):
+    from pyflow_hip import ops
+    from pyflow_hip.plan import SequencePlan
+    B, Dh = 2, Hh * 64
+    plan = SequencePlan(clips, _mask(), [16, 24, 24], DEV)
+    L, Lp = plan.L, plan.Lp
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    qkv = torch.randn(B, L, 3 * Dh, generator=g, device=DEV)
+    qkv[..., 2 * Dh:] *= 0.125 * ops.LOG2E
+    q, k = qkv[..., 2 * Dh:], qkv[..., :Dh]
+    if case in ("overflow", "mixed"):
+        q[:, 700:900] += 2.0
+        k[:, 1000:1040] += 3.0
+    if case in ("underflow", "mixed"):
+        q[:, 2000:2200] -= 3.0
+        k += 1.3
+    return plan, qkv.to(torch.bfloat16), B, Dh, L, Lp
+
+
+def _attend(qkv, plan, B, Hh, Dh, L, Lp, q_row_begin=0, scratch=True, out=None):
+    """out-of-place attention through the C ABI; scratch=False: no workspace offered -> the 128-row kernel"""
+    from pyflow_hip import lib, ops
+    vT = torch.zeros(B, Hh, 64, Lp, dtype=torch.bfloat16, device=DEV)
+    ops.v_transpose(qkv, vT, Dh, 3 * Dh, L * 3 * Dh, B, Hh, L, Lp)
+    out = torch.zeros(B, L, Dh, dtype=torch.bfloat16, device=DEV) if out is None else out
+    d = lib.AttnDesc()
+    d.Q, d.K, d.Vt, d.O = qkv.data_ptr() + 2 * 2 * Dh, qkv.data_ptr(), vT.data_ptr(), out.data_ptr()
+    d.ldq = d.ldk = 3 * Dh
+    d.ldo = Dh
+    d.strideQ = d.strideK = L * 3 * Dh
+    d.strideO = L * Dh
+    d.strideVt_b, d.strideVt_h = Hh * 64 * Lp, 64 * Lp
+    d.B, d.H, d.L, d.Lp, d.Lt = B, Hh, L, Lp, LT
+    d.a_lo, d.a_hi, d.b_hi = plan.a_lo.data_ptr(), plan.a_hi.data_ptr(), plan.b_hi.data_ptr()
+    d.tile_kv_end = plan.tile_kv_end.data_ptr()
+    d.scale, d.q_prescaled, d.q_row_begin = 0.125, 1, q_row_begin
+    if scratch:
+        need = int(lib.load().pf_attention_workspace_bytes(C.c_int(B), C.c_int(Hh), C.c_int(L)))
+        ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), need)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    which = lib.load().pf_attention_which(C.byref(d))
+    lib.check(lib.load().pf_attention_bf16(C.byref(d), lib.stream()))
+    return out, which
+
+
+def _dense_ref(qkv, plan, B, Hh, Dh, L, rows):
+    dm = torch.from_numpy(plan.dense_mask()[:, rows]).to(DEV)
+    q = qkv[:, rows, 2 * Dh:].float().view(B, len(rows), Hh, 64).transpose(1, 2)
+    k = qkv[..., :Dh].float().view(B, L, Hh, 64).transpose(1, 2)
+    v = qkv[..., Dh:2 * Dh].float().view(B, L, Hh, 64).transpose(1, 2)
+    s = torch.einsum("bhrd,bhld->bhrl", q, k) * 0.6931471805599453
+    s = s.masked_fill(~dm[:, None], float("-inf"))
+    return torch.einsum("bhrl,bhld->bhrd", torch.softmax(s, -1), v).transpose(1, 2).reshape(B, len(rows), Dh)
+
+
+@pytest.mark.parametrize("case", ["benign", "overflow", "underflow", "mixed"])
+def test_kv_split_pair_few_heads_every_row(case):
+    """6 heads x 2 x 12 query tiles = 144 workgroups at L = 3 008: the key range of every query tile is cut into 4 parts (SPLIT),
+    the parts are added and range-checked (COMBINE), flagged waves recomputed (FIXUP).  Every row against the dense fp32
+    reference (1e-2, one attention op) and against the 128-row kernel."""
+    Hh = 6
+    plan, qkv, B, Dh, L, Lp = _few_heads_case(Hh, CLIPS, case, 11)
+    out, which = _attend(qkv, plan, B, Hh, Dh, L, Lp)
+    assert which == 64 + 4
+    assert torch.isfinite(out.float()).all()
+    ref = _dense_ref(qkv, plan, B, Hh, Dh, L, list(range(L)))
+    err = rel_l2(out.float().cpu(), ref.cpu())
+    print(f"KV-split pair, 6 heads, L = 3008, {case}: rel-L2 vs dense fp32 reference {err:.3e}")
+    assert err < 1e-2
+    out32, which32 = _attend(qkv, plan, B, Hh, Dh, L, Lp, scratch=False)
+    assert which32 == 32 and rel_l2(out.float().cpu(), out32.float().cpu()) < 5e-3
+    again, _ = _attend(qkv, plan, B, Hh, Dh, L, Lp)
+    assert torch.equal(out, again)                       # parts are added in part order: repeatable
+
+
+def test_kv_split_pair_rank_shape_at_the_headline_length():
+    """a sequence-parallel rank at P = 8: 4 heads, batch 2, L = 15 488 -> 488 workgroups, each query tile in 2 key ranges;
+    sampled rows against fp32, the last-block form (q_row_begin on an odd 128-row tile) leaves the rows below untouched"""
+    Hh = 4
+    clips = [(28, 24, 40), (1, 48, 80), (1, 96, 160), (1, 96, 160)]
+    plan, qkv, B, Dh, L, Lp = _few_heads_case(Hh, clips, "benign", 12)
+    assert L == 15488
+    out, which = _attend(qkv, plan, B, Hh, Dh, L, Lp)
+    assert which == 64 + 2
+    rows = [0, 39, 40, 127, 128, 367, 368, 6847, 6848, 7807, 7808, 11647, 11648, 15487]
+    ref = _dense_ref(qkv, plan, B, Hh, Dh, L, rows)
+    assert rel_l2(out[:, rows].float().cpu(), ref.cpu()) < 1e-2
+    out32, _ = _attend(qkv, plan, B, Hh, Dh, L, Lp, scratch=False)
+    assert rel_l2(out.float().cpu(), out32.float().cpu()) < 5e-3
+    r0 = L - plan.n_cur
+    tail = torch.full_like(out, 7.0)
+    tail, wt = _attend(qkv, plan, B, Hh, Dh, L, Lp, q_row_begin=r0, out=tail)
+    assert wt > 64                                         # 16 query tiles x 8 = 128 workgroups -> 4 parts
+    assert (tail[:, :r0].float() == 7.0).all()
+    assert rel_l2(tail[:, r0:].float().cpu(), out[:, r0:].float().cpu()) < 2e-3      # other part boundaries: fp32 summation order
