@@ -103,27 +103,35 @@ def main():
     mask[1, :96] = 1
     enc = torch.randn(2, 128, 4096).to(torch.bfloat16)
     pooled = torch.randn(2, 768)
+    pooled1 = pooled[1:2].contiguous()
     eng.encode_context(enc)
     units = sorted({int(x) for x in args.units.split(",")} | {0, 30})
     Ps = [int(x) for x in args.ranks.split(",")]
     d, B = 1920, 2
     link = args.link_gbs * 1e9 * args.link_eff
 
-    def measure(P, r, u, s):
-        """device ms, host ms of one forward of rank r of P at (u, s), and its kernel-family split"""
+    state = {"B": 2}
+
+    def measure(P, r, u, s, nb=2):
+        """device ms, host ms of one forward of rank r of P at (u, s), and its kernel-family split.  nb = 1: ONE branch of the
+        guidance pair (the guidance-parallel engine of N = 2, pyflow_hip/flux_cfg.py: all rows, all heads, batch 1)"""
         eng.comm = PhantomComm(r, P)
         eng._layouts = {}
+        if state["B"] != nb:
+            eng.encode_context(enc if nb == 2 else enc[1:2])
+            state["B"] = nb
         shapes = clips_for(u, s)
         clips = [torch.randn(1, 16, *c, device=dev) for c in shapes]
-        plan = eng.make_plan(shapes, mask)
+        plan = eng.make_plan(shapes, mask if nb == 2 else mask[1:2])
+        ts_, pooled_ = ([500.0, 500.0], pooled) if nb == 2 else ([500.0], pooled1)
         for _ in range(2):                                   # records the launch list, then one replay
-            eng.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True)
+            eng.forward_tokens(plan, clips, ts_, pooled_, shared_clips=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         h0 = time.perf_counter()
         e0.record()
         for _ in range(args.reps):
-            eng.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True)
+            eng.forward_tokens(plan, clips, ts_, pooled_, shared_clips=True)
         e1.record()
         host_ms = (time.perf_counter() - h0) / args.reps * 1e3          # launch loop only (the device runs behind)
         torch.cuda.synchronize()
@@ -131,7 +139,7 @@ def main():
         # one profiled (eager, per-launch events) forward for the family split
         ops.PROFILER.records = {}
         ops.PROFILER.enabled = True
-        eng.forward_tokens(plan, clips, [500.0, 500.0], pooled, shared_clips=True)
+        eng.forward_tokens(plan, clips, ts_, pooled_, shared_clips=True)
         ops.PROFILER.enabled = False
         torch.cuda.synchronize()
         fam = {}
@@ -159,6 +167,13 @@ def main():
         return full, hidden
 
     table = {}
+    if 2 in Ps:          # guidance-parallel N = 2: a rank = the whole sequence, all heads, ONE branch of the CFG pair
+        for s in range(3):
+            for u in units:
+                dev_ms, host_ms, fam, nloc, mh = measure(1, 0, u, s, nb=1)
+                L = 128 + sum(c[0] * (c[1] // 2) * (c[2] // 2) for c in clips_for(u, s))
+                table[("g2", 0, u, s)] = dict(dev_ms=dev_ms, host_ms=host_ms, fam=fam, L=L, nloc=nloc, heads=mh)
+                print(f"guidance2 (batch 1) u={u:2d} s={s} L={L:5d}: {dev_ms:8.3f} ms device, {host_ms:6.3f} ms host", flush=True)
     for P in Ps:
         for r in sorted({0, P - 1}):
             for s in range(3):
@@ -181,9 +196,12 @@ def main():
     result = {"assumptions": dict(link_GBs=args.link_gbs, link_eff=args.link_eff, latency_us=args.latency_us,
                                   decode_s_single_gpu=args.decode_s, units_sampled=units, reps=args.reps), "P": {}}
     base = None
-    for P in Ps:
+    modes = list(Ps) + (["g2"] if 2 in Ps else [])
+    for P in modes:
+        guidance = P == "g2"
+        Pn = 2 if guidance else P
         per_rank = {}
-        for r in sorted({0, P - 1}):
+        for r in ([0] if guidance else sorted({0, P - 1})):
             dev_s = host_s = full_s = hid_s = 0.0
             fam_s = {}
             for u in range(31):
@@ -192,8 +210,8 @@ def main():
                     dm = interp(P, r, s, u, lambda e: e["dev_ms"])
                     hm = interp(P, r, s, u, lambda e: e["host_ms"])
                     L = 128 + sum(c[0] * (c[1] // 2) * (c[2] // 2) for c in clips_for(u, s))
-                    nloc = -(-L // P)
-                    cf, ch = comm_ms(P, L, nloc)
+                    nloc = -(-L // Pn)
+                    cf, ch = (0.0, 0.0) if guidance else comm_ms(P, L, nloc)
                     dev_s += steps * dm * 1e-3
                     host_s += steps * hm * 1e-3
                     full_s += steps * cf * 1e-3
@@ -203,23 +221,23 @@ def main():
             per_rank[r] = dict(device_s=round(dev_s, 3), host_s=round(host_s, 3), exchange_s_exposed=round(full_s, 3),
                                exchange_s_overlapped=round(hid_s, 3), kernel_family_s={k: round(v, 3) for k, v in sorted(fam_s.items())})
         worst = max(per_rank.values(), key=lambda e: e["device_s"])
-        dec = args.decode_s * (-(-7 // P)) / 7.0
+        dec = args.decode_s * (-(-7 // Pn)) / 7.0
         t_lo = max(worst["device_s"], worst["host_s"]) + worst["exchange_s_overlapped"] + dec
         t_hi = max(worst["device_s"], worst["host_s"]) + worst["exchange_s_exposed"] + dec
         if P == 1:
             base = t_lo
         result["P"][P] = dict(ranks=per_rank, decode_s=round(dec, 3), video_s=[round(t_lo, 2), round(t_hi, 2)],
                               frames_per_s=[round(241 / t_hi, 2), round(241 / t_lo, 2)],
-                              compute_efficiency=round(per_rank[0]["device_s"] and (result["P"][Ps[0]]["ranks"][0]["device_s"] / (P * worst["device_s"])) if P != Ps[0] else 1.0, 3),
-                              efficiency=[round(base / (P * t_hi), 3), round(base / (P * t_lo), 3)] if base else None)
+                              compute_efficiency=round(per_rank[0]["device_s"] and (result["P"][Ps[0]]["ranks"][0]["device_s"] / (Pn * worst["device_s"])) if P != Ps[0] else 1.0, 3),
+                              efficiency=[round(base / (Pn * t_hi), 3), round(base / (Pn * t_lo), 3)] if base else None)
     print("\nP   rank  device s  host s  exch exposed / overlapped s  decode s  video s (lo..hi)  frames/s  efficiency  compute eff.")
-    for P in Ps:
+    for P in modes:
         e = result["P"][P]
         for r, pr in e["ranks"].items():
-            print(f"{P:<3d} {r:<5d} {pr['device_s']:8.2f} {pr['host_s']:7.2f}   {pr['exchange_s_exposed']:7.2f} / {pr['exchange_s_overlapped']:<7.2f}"
+            print(f"{str(P):<3s} {r:<5d} {pr['device_s']:8.2f} {pr['host_s']:7.2f}   {pr['exchange_s_exposed']:7.2f} / {pr['exchange_s_overlapped']:<7.2f}"
                   f"          {e['decode_s']:6.2f}   {e['video_s'][0]:6.2f}..{e['video_s'][1]:<6.2f}  {e['frames_per_s'][0]:5.2f}..{e['frames_per_s'][1]:<5.2f} "
                   f" {e['efficiency']}  {e['compute_efficiency']}")
-    for P in Ps:
+    for P in modes:
         print(f"P={P} kernel-family seconds per video, slowest rank:",
               max(result["P"][P]["ranks"].values(), key=lambda e: e["device_s"])["kernel_family_s"])
     if args.out:
