@@ -79,10 +79,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     // ---- tile
     const int tiles_x = p.Wd / PW, tiles_y = p.H / PH;
     int tile = blockIdx.x;
+    const int nblk = blockIdx.y;                     // block of 128 filters (N = 128 gridDim.y)
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y; const int t = tile / tiles_y;
     const int y0 = ty * PH, x0 = tx * PW;
-    const int nq = p.cin >> 5, lq = p.cin == 256 ? 3 : 2;      // 32-channel quarters per temporal tap: 4 or 8 = 1 << lq
+    const int nq = p.cin >> 5, lq = p.cin == 512 ? 4 : (p.cin == 256 ? 3 : 2);      // 32-channel quarters per temporal tap: 4 / 8 / 16 = 1 << lq
     const int NSTAGE = 3 * nq, NSTEP = NSTAGE * 9;   // (dt, quarter) stages x 9 spatial taps
     const int pix = p.cin * 2;                       // bytes per input pixel / per filter tap
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
         wsrc = (unsigned)(n * (27 * pix) + c * 16);
     }
     const char* const Xb = (const char*)(p.X + p.in_base_off) + ((long long)t * p.Hp * p.Wp + (long long)y0 * p.Wp + x0) * pix;
-    const char* const Wb = (const char*)p.W;
+    const char* const Wb = (const char*)p.W + (long long)nblk * 128 * 27 * pix;      // this block's 128 filter rows
 
     auto issue_halo = [&](int stage, int k) {        // piece k of this wave for (dt, q) = (stage / nq, stage % nq)
         const int dt = stage >> lq, q = stage & (nq - 1);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     float* const s_stat = (float*)smem;                // [wave 0..7][hsel][fc][e][2]: 8 x 64 x 2 floats = 4 KiB
 #pragma unroll
     for (int hsel = 0; hsel < 2; ++hsel) {
-        const int n = 64 * wn + 32 * hsel + 8 * fc;
+        const int n = 128 * nblk + 64 * wn + 32 * hsel + 8 * fc;
         const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
         float gs[8], gq[8];
 #pragma unroll
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) sum += s_stat[(((wn_ * 4 + w) * 2 + hsel) * 4 + fc_) * 16 + 2 * e + k];
-            atomicAdd(p.gn_stats + ((long long)t * p.gn_C + c) * 2 + k, (double)sum);
+            atomicAdd(p.gn_stats + ((long long)t * p.gn_C + 128 * nblk + c) * 2 + k, (double)sum);
         }
     }
 }
@@ -290,11 +291,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
 
 }  // namespace
 
-// 3 x 3 x 3 taps, 128 or 256 input channels (= the input pitch), 128 filters all valid, plain output map, unit strides,
-// frames that are whole numbers of 16 x 32 patches; bias required (the decoder's convs all have one)
-bool pf_conv_halo_supports(const pf_conv_desc* d) {
-    if (d->kt != 3 || d->kh != 3 || d->kw != 3 || (d->Cin != 128 && d->Cin != 256) || d->N != 128 || !d->bias) return false;
-    if ((d->n_valid > 0 ? d->n_valid : d->N) != 128 || d->Cg != 128 || d->Cout_pitch % 8) return false;
+// 3 x 3 x 3 taps, 128 / 256 / 512 input channels (= the input pitch), N = a multiple of 128 filters, all valid (one 128-filter
+// block per blockIdx.y: the input halo is staged once per block), plain output map, unit strides, frames that are whole
+// numbers of 16 x 32 patches; bias required (the decoder's convs all have one).  `wide` = the caller accepts N > 128.
+bool pf_conv_halo_supports(const pf_conv_desc* d, bool wide) {
+    if (d->kt != 3 || d->kh != 3 || d->kw != 3 || (d->Cin != 128 && d->Cin != 256 && d->Cin != 512) || !d->bias) return false;
+    if (d->N % 128 || d->N <= 0 || (!wide && (d->N != 128 || d->Cin == 512))) return false;
+    if ((d->n_valid > 0 ? d->n_valid : d->N) != d->N || d->Cg != d->N || d->Cout_pitch % 8) return false;
+    // a launch of at least half a round of the chip (the small 32 x 32 / 64 x 64-pixel layers stay with the implicit GEMM)
+    if (d->N > 128 && (long long)d->T * (d->H / 16) * (d->W_ / 32) * (d->N / 128) < 128) return false;
     if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->out_t_shift != 0) return false;
     if ((d->in_sh > 1) || (d->in_sw > 1) || (d->in_st > 1)) return false;
     if (d->H % 16 || d->W_ % 32 || d->T <= 0) return false;
@@ -316,6 +321,6 @@ int pf_conv_halo_launch(const pf_conv_desc* d, double* gn_stats, int gn_C, hipSt
     a.in_base_off = d->in_base_off; a.out_base_off = d->out_base_off;
     a.gn_stats = gn_stats; a.gn_C = gn_C;
     const int grid = d->T * (d->H / PH) * (d->W_ / PW);
-    hipLaunchKernelGGL(conv_halo128_kernel<1>, dim3(grid), dim3(512), SMEM, stream, a);
+    hipLaunchKernelGGL(conv_halo128_kernel<1>, dim3(grid, d->N / 128), dim3(512), SMEM, stream, a);
     return 0;
 }

@@ -271,7 +271,7 @@ long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
 int pf_conv_narrow_launch(const pf_conv_desc* d, hipStream_t stream);
-bool pf_conv_halo_supports(const pf_conv_desc* d);                         // convhalo.hip: 3x3x3, 128 filters, 128 / 256 input channels
+bool pf_conv_halo_supports(const pf_conv_desc* d, bool wide);              // convhalo.hip: 3x3x3, N % 128 == 0, 128 / 256 / 512 input channels
 int pf_conv_halo_launch(const pf_conv_desc* d, double* gn_stats, int gn_C, hipStream_t stream);
 
 // tile-width policy of the 256-row ping-pong kernels: 0 (auto, default) | 128 | 192 | 256 (that width when it divides N) | -1 (never)
@@ -280,7 +280,8 @@ static int gemm256_force() { return g_gemm256_force; }
 // gemm8p (persistent 256 x 256 tiles): 1 = whenever legal (policy 8), 0 = automatic, -1 = never (policy -8)
 static int g_gemm8p_mode = 0;
 static bool g_narrow_enabled = true;         // pf_gemm_set_policy(-3) / (3): never / again the narrow-N conv kernel
-static bool g_halo_enabled = true;           // pf_gemm_set_policy(-5) / (5): never / again the LDS-halo direct conv (N = 128 layers)
+static bool g_halo_enabled = true;           // pf_gemm_set_policy(-5) / (5): never / again the LDS-halo direct conv
+static bool g_halo_wide = true;              // pf_gemm_set_policy(-6) / (6): only the N = 128 layers / also the 256- and 512-filter layers
 static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
 // 1 = a launch of >= 192 tiles (whole rounds + tail), 2 = a MID-SIZE launch (32 .. 128 tiles, e.g. a sequence-parallel rank's
@@ -308,9 +309,10 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 3 || force == -3) { g_narrow_enabled = force > 0; return 0; }
     if (force == 4 || force == -4) { pf_gemm8p_set_tail_split(force > 0); return 0; }
     if (force == 5 || force == -5) { g_halo_enabled = force > 0; return 0; }
+    if (force == 6 || force == -6) { g_halo_wide = force > 0; return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, 2, -2, 3, -3, 4, -4, 5, -5, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-6, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
@@ -433,7 +435,7 @@ static void conv_args(const pf_conv_desc* d, Args& a) {
 // 0 = gemm_kernel<true>
 static int conv_route(const pf_conv_desc* d, const Args& a) {
     if (g_narrow_enabled && pf_conv_narrow_supports(d)) return -1;
-    if (g_halo_enabled && gemm256_force() == 0 && pf_conv_halo_supports(d)) return -2;
+    if (g_halo_enabled && gemm256_force() == 0 && pf_conv_halo_supports(d, g_halo_wide)) return -2;
     if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) return 8;
     return pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force());
 }

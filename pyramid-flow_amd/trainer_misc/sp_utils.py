@@ -10,13 +10,15 @@ def is_sequence_parallel_initialized():
     return _sp.is_sequence_parallel_initialized()
 
 
-def init_sequence_parallel_group(args):
+def init_sequence_parallel_group(args, guidance_parallel=False):
     """:21-47: consecutive-rank groups of `args.sp_group_size` over the first `args.sp_proc_num` processes
-    (-1 = all of them); must run before the model is built (the engines pick their sequence-parallel form then)."""
+    (-1 = all of them); must run before the model is built (the engines pick their sequence-parallel form then).
+    guidance_parallel (not a reference option, a world of two only): the ranks split the classifier-free-guidance pair
+    instead of the sequence (pyflow_hip/flux_cfg.py)."""
     assert not _sp.is_sequence_parallel_initialized(), "sequence parallel group is already initialized"
     assert dist.is_available() and dist.is_initialized(), "The pytorch distributed should be initialized"
     print(f"Setting the Sequence Parallel Size {args.sp_group_size}")
-    _sp.init_sequence_parallel_group(args)
+    _sp.init_sequence_parallel_group(args, guidance_parallel=guidance_parallel)
 
 
 def get_sequence_parallel_group():

@@ -102,12 +102,13 @@ def test_pair_runs_for_the_benchmark_shapes_and_matches_dense_reference():
     lib.check(lib.load().pf_attention_bf16(C.byref(d), lib.stream()))
     assert rel_l2(out32.float().cpu(), ref.cpu()) < 1e-2
     assert rel_l2(out.float().cpu(), out32.float().cpu()) < 5e-3
-    # last-block form: rows below q_row_begin are not needed.  The remaining rows are too few workgroups for the pair
-    # here (4 x 60 of 256 rows), so the 32-row kernel serves them: identical to its full run, close to the pair's rows
+    # last-block form: rows below q_row_begin are not needed.  The remaining rows are 4 x 60 = 240 workgroups of 256 rows: since
+    # round 4 the pair takes them with every query tile's key range cut in two (KV split); rows below q_row_begin untouched
     r0 = L - plan.n_cur
     tail = _run(qkv, plan, B, L, Lp, q_row_begin=r0)
-    assert torch.equal(tail[:, r0:], out32[:, r0:])
-    assert rel_l2(tail[:, r0:].float().cpu(), out[:, r0:].float().cpu()) < 5e-3
+    assert (tail[:, :r0] == 0).all()
+    assert rel_l2(tail[:, r0:].float().cpu(), out[:, r0:].float().cpu()) < 2e-3
+    assert rel_l2(tail[:, r0:].float().cpu(), out32[:, r0:].float().cpu()) < 5e-3
 
 
 @pytest.mark.parametrize("case", ["overflow", "underflow", "mixed"])

@@ -35,12 +35,13 @@ def _desc_route(src, dst, cw, T, res=None):
     return int(L_.load().pf_conv3d_which(C.byref(d)))
 
 
-@pytest.mark.parametrize("Ci,with_res,T,H,W", [(128, False, 3, 64, 64), (128, True, 8, 256, 256), (256, False, 2, 64, 96),
-                                              (256, True, 1, 32, 32), (128, True, 2, 16, 32)])
-def test_halo_conv_vs_fp32_conv3d_and_vs_implicit_gemm(Ci, with_res, T, H, W):
+@pytest.mark.parametrize("Ci,with_res,T,H,W,co", [(128, False, 3, 64, 64, 128), (128, True, 8, 256, 256, 128), (256, False, 2, 64, 96, 128),
+                                                 (256, True, 1, 32, 32, 128), (128, True, 2, 16, 32, 128),
+                                                 # the 256- / 512-filter resnets of up_blocks.2 / .1 (one 128-filter block per blockIdx.y)
+                                                 (256, True, 4, 128, 128, 256), (512, False, 2, 128, 128, 256), (512, True, 8, 64, 64, 512)])
+def test_halo_conv_vs_fp32_conv3d_and_vs_implicit_gemm(Ci, with_res, T, H, W, co):
     from pyflow_hip import ops
     from pyflow_hip.vae import PBuf, ConvW, conv
-    co = 128
     g = torch.Generator().manual_seed(7 * Ci + T)
     x = torch.randn(T + 2, H, W, Ci, generator=g).to(torch.bfloat16)            # frames 0, 1 = the cache slots (previous chunk)
     w = (torch.randn(co, Ci, 3, 3, 3, generator=g) * 0.03).to(torch.bfloat16)
@@ -60,7 +61,8 @@ def test_halo_conv_vs_fp32_conv3d_and_vs_implicit_gemm(Ci, with_res, T, H, W):
         ops.gemm_set_policy(5 if halo else -5)
         try:
             dst = PBuf("y", T, H, W, co, "cuda")
-            assert _desc_route(src, dst, cw, T, res) == (-2 if halo else 128) or (not halo and T * H * W < 65536)
+            rt = _desc_route(src, dst, cw, T, res)
+            assert (rt == -2) == halo, rt
             stats = torch.zeros(T * co * 2, dtype=torch.float64, device="cuda")
             conv(src, dst, cw, T, res=res, gn_stats=stats)
             y = dst.t.view(T + 2, H + 2, W + 2, dst.Cp)[2:, 1:-1, 1:-1, :co].clone()
@@ -102,6 +104,8 @@ def test_halo_route_only_where_the_kernel_applies():
         return _desc_route(src, dst, cw, 2)
     assert route(128, 128, 256, 256) == -2 and route(256, 128, 256, 256) == -2
     assert route(128, 128, 48, 40) != -2            # frames that are not whole 16 x 32 patches
-    assert route(128, 256, 128, 128) != -2          # 256 filters: the wide implicit-GEMM kernels
-    assert route(512, 128, 64, 64) != -2            # other input widths
+    assert route(128, 192, 128, 128) != -2          # filter counts that are not whole 128-blocks
+    assert route(512, 512, 32, 32) != -2            # wide layers with too few patches for half a round of the chip (T = 2)
+    assert route(256, 256, 128, 128) == -2          # the 256-filter resnets at 128 x 128
+    assert route(384, 128, 64, 64) != -2            # other input widths
     assert route(128, 128, 64, 64, k=1) != -2       # 1 x 1 x 1 shortcut convs
