@@ -145,8 +145,10 @@ int pf_conv3d_which(const pf_conv_desc* d);
  * (flux_block.py:361-365, 597-599; modeling_pyramid_flux.py:318-350).  The mask is implicit: query
  * row i may see keys j in [a_lo[i], a_hi[i]) for j < Lt (text part) and keys Lt <= j < b_hi[i]
  * (image part).  tile_kv_end[b][qt] = max b_hi over the 128-row q tile qt (and >= Lt if any text key
- * is visible).  Q/K are token-major (row stride ldq/ldk, head h at column h*64); Vt is the image
- * written by pf_v_transpose: [B][H][64][Lp], keys permuted inside groups of 16.  O may alias Q. */
+ * is visible).  Q/K are token-major (row stride ldq/ldk, head h at column h*64).  V: either token-major like K (ABI 4:
+ * `V`, `ldv`, `strideV`, head stride = head_stride_qk; the kernels transpose it on the way out of LDS with
+ * ds_read_b64_tr_b16 -- no extra pass, what the engines use), or, with V = NULL, `Vt` = the image written by
+ * pf_v_transpose: [B][H][64][Lp], keys permuted inside groups of 16.  O may alias Q. */
 typedef struct {
     const void* Q; const void* K; const void* Vt; void* O;
     int ldq, ldk, ldo;
@@ -169,6 +171,11 @@ typedef struct {
      * attention launches that may overlap. */
     void* workspace;
     long long workspace_bytes;
+    /* ABI 4: V token-major (NULL = use Vt).  Row stride ldv (elements, % 8 == 0), batch stride strideV, heads at the same
+     * stride as in Q / K (head_stride_qk). */
+    const void* V;
+    int ldv;
+    long long strideV;
 } pf_attn_desc;
 int pf_attention_bf16(const pf_attn_desc* d, pf_stream_t stream);
 long long pf_attention_workspace_bytes(int B, int H, int L);

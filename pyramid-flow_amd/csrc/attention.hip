@@ -27,8 +27,29 @@ constexpr int ABUF = 2 * KTILE;        // K + V^T
 constexpr float NEG = -1.0e30f;
 constexpr float DEFER = 6.0f;        // log2 units: P stays below 2^6 between rescales
 
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef short v8s_t __attribute__((ext_vector_type(8)));
+// V fragment of the PV MFMA (32x32x16 A operand: lane -> feature lane % 32 of a 32-feature half, 8 keys) straight from a
+// ROW-MAJOR V tile in LDS ([64 keys][64 features], 128-byte rows, 16-byte chunk c of key k stored at c ^ 4 ((k >> 1) & 1)):
+// ds_read_b64_tr_b16 hands lane t of a 16-lane group column t of the [4 keys][16 features] block whose rows the group's
+// lanes address (lane s: key s / 4, features 4 (s % 4) ..; profiles/r04_ds_read_tr_b16_probe.log), so two of them return the
+// keys 16 g + 4 hi + {0..3} and 16 g + 8 + 4 hi + {0..3} of this lane's feature -- the contraction order of the P fragment
+// (C-layout rows of S^T), which the V^T image of pf_v_transpose had to mirror with a key permutation.  `lane_off` =
+// vrow_lane_offset(lane, i) for feature half i, `tile` = the V tile, g = 16-key slot.
+PF_DEVICE unsigned vrow_lane_offset(int lane, int i) {
+    const int kk = (lane & 15) >> 2, hi = lane >> 5, a = (lane >> 4) & 1, b = (lane & 3) >> 1;
+    return (unsigned)((4 * hi + kk) * 128 + (((((i ^ (kk >> 1)) << 2) | (a << 1) | b)) << 4) + 8 * (lane & 1));
+}
+PF_DEVICE bf16x8_t vrow_fragment(const char* tile, unsigned lane_off, int g) {
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + lane_off + (16 * g) * 128));
+    const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + lane_off + (16 * g + 8) * 128));
+    const v8s_t v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 struct AArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+    const bf16_t* V; int ldv, hs_v; long long sV;      // VROW kernels: V token-major like K (row stride ldv, head stride hs_v)
     int ldq, ldk, ldo;
     long long sQ, sK, sO, sVb, sVh;
     int Lp, L, H, B, Lt, nqt;
@@ -46,7 +67,7 @@ struct AArgs {
     int* part_flags;            // [unit][wave]: the part produced a non-finite sum
 };
 
-template <bool PRE, int ILP, int OCC>
+template <bool PRE, int ILP, int OCC, bool VROW = false>
 __global__ __launch_bounds__(256, OCC) void attn_kernel(const AArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -85,14 +106,16 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AArgs p) {
 
     // ---- DMA sources: wave owns pieces i = wid*2 + j (rows 8i..8i+7) of the K and V^T tiles ----
     const bf16_t* kbase = p.K + (long long)b * p.sK + h * p.hs_qk;
-    const bf16_t* vbase = p.Vt + (long long)b * p.sVb + (long long)h * p.sVh;
-    int prow[2], pc[2];
+    const bf16_t* vbase = VROW ? p.V + (long long)b * p.sV + h * p.hs_v : p.Vt + (long long)b * p.sVb + (long long)h * p.sVh;
+    int prow[2], pc[2], pcv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = wid * 2 + j;
         prow[j] = 8 * i + (lane >> 3);
         pc[j] = ((lane & 7) ^ (((i & 1) << 2) + (lane >> 4))) * 8;
+        pcv[j] = ((lane & 7) ^ (((prow[j] >> 1) & 1) << 2)) * 8;       // row-major V tile: chunk c of key k at c ^ 4 ((k >> 1) & 1)
     }
+    const unsigned vtr0 = vrow_lane_offset(lane, 0), vtr1 = vrow_lane_offset(lane, 1);
     auto issue = [&](int jt, int buf) {
         const int j0 = jt * KB;
         char* base = smem + buf * ABUF + wid * 2048;
@@ -103,8 +126,15 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AArgs p) {
             glds16(kbase + (long long)key * p.ldk + pc[j], base + j * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            glds16(vbase + (long long)prow[j] * p.Lp + j0 + pc[j], base + KTILE + j * 1024);
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (VROW) {
+                int key = j0 + prow[j];
+                key = key < p.L ? key : p.L - 1;
+                glds16(vbase + (long long)key * p.ldv + pcv[j], base + KTILE + j * 1024);
+            } else {
+                glds16(vbase + (long long)prow[j] * p.Lp + j0 + pc[j], base + KTILE + j * 1024);
+            }
+        }
     };
 
     f32x16_t o[2];
@@ -162,9 +192,14 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AArgs p) {
         bf16x8_t vf[2][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ch = ((2 * g + hi) ^ swz) << 4;
+            if constexpr (VROW) {
+                vf[0][g] = vrow_fragment(sv, vtr0, g);
+                vf[1][g] = vrow_fragment(sv, vtr1, g);
+            } else {
+                const int ch = ((2 * g + hi) ^ swz) << 4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) vf[i][g] = *(const bf16x8_t*)(sv + (i * 32 + frow) * 128 + ch);
+                for (int i = 0; i < 2; ++i) vf[i][g] = *(const bf16x8_t*)(sv + (i * 32 + frow) * 128 + ch);
+            }
         }
         if (has_text || (j0 + KB > wmin_s)) {        // scalar: tile straddles a visibility boundary of some row
 #pragma unroll
@@ -395,7 +430,9 @@ extern "C" int pf_attention_which(const pf_attn_desc* d) {
 }
 
 extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
-    if (!d || !d->Q || !d->K || !d->Vt || !d->O) return pf_set_err("pf_attention_bf16: null operand");
+    if (!d || !d->Q || !d->K || (!d->Vt && !d->V) || !d->O) return pf_set_err("pf_attention_bf16: null operand");
+    const bool vrow = d->V != nullptr;
+    if (vrow && (d->ldv % 8)) return pf_set_err("pf_attention_bf16: ldv must be a multiple of 8");
     if (d->L <= 0 || d->B <= 0 || d->H <= 0) return pf_set_err("pf_attention_bf16: empty problem");
     if (d->Lp % 64 || d->Lp < d->L) return pf_set_err("pf_attention_bf16: Lp must be a multiple of 64 and >= L");
     if ((d->ldq % 8) || (d->ldk % 8) || (d->ldo % 4)) return pf_set_err("pf_attention_bf16: bad leading dims");
@@ -408,6 +445,7 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
     a.a_lo = d->a_lo; a.a_hi = d->a_hi; a.b_hi = d->b_hi; a.tile_kv_end = d->tile_kv_end;
     a.sc = d->scale * 1.4426950408889634f;
     a.hs_qk = d->head_stride_qk > 0 ? d->head_stride_qk : HD;
+    a.V = (const bf16_t*)d->V; a.ldv = d->ldv; a.sV = d->strideV; a.hs_v = a.hs_qk;
     if (a.hs_qk % 8) return pf_set_err("pf_attention_bf16: head_stride_qk must be a multiple of 8");
     a.prio = 1;              // s_setprio around the MFMA groups (measured best of {none, MFMA, softmax}: profiles/r01_attention_variants.log)
     a.qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
@@ -429,29 +467,47 @@ extern "C" int pf_attention_bf16(const pf_attn_desc* d, hipStream_t stream) {
             a.part_flags = (int*)reg;
             a.parts = (float*)(reg + (long long)SPLIT_UNITS * 4 * 16);
             if ((long long)grid64 * sp > SPLIT_UNITS) return pf_set_err("pf_attention_bf16: split units exceed the scratch");
-            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33 | 64>), SM64);
             PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33 | 128>), SM64);
-            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
-            hipLaunchKernelGGL((attn64_kernel<2, 33 | 64>), dim3(grid64 * sp), dim3(256), SM64, stream, a);
-            hipLaunchKernelGGL((attn64_kernel<2, 33 | 128>), dim3(grid64), dim3(256), SM64, stream, a);
-            hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
+            if (vrow) {
+                PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33 | 64, 4, true>), SM64);
+                PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4, 4, true>), SM64);
+                hipLaunchKernelGGL((attn64_kernel<2, 33 | 64, 4, true>), dim3(grid64 * sp), dim3(256), SM64, stream, a);
+                hipLaunchKernelGGL((attn64_kernel<2, 33 | 128>), dim3(grid64), dim3(256), SM64, stream, a);
+                hipLaunchKernelGGL((attn64_kernel<2, 4, 4, true>), dim3(grid64), dim3(256), SM64, stream, a);
+            } else {
+                PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33 | 64>), SM64);
+                PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
+                hipLaunchKernelGGL((attn64_kernel<2, 33 | 64>), dim3(grid64 * sp), dim3(256), SM64, stream, a);
+                hipLaunchKernelGGL((attn64_kernel<2, 33 | 128>), dim3(grid64), dim3(256), SM64, stream, a);
+                hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
+            }
             hipError_t es = hipGetLastError();
             if (es != hipSuccess) return pf_set_err(hipGetErrorString(es));
             return 0;
         }
         // FAST | MMSUM (33): row sums on the matrix pipe, +1.5 % (L = 15 488) ... +3 % (L = 3 008) over the v_add_f32 sums
         // (mode 1) in the same-box A/B of profiles/r04_attention_rowsum_variants.log; the v_dot2c / v_pk_add forms lose 2-3 %
-        PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33>), SM64);
-        PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
-        hipLaunchKernelGGL((attn64_kernel<2, 33>), dim3(grid64), dim3(256), SM64, stream, a);
-        hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
+        if (vrow) {
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33, 4, true>), SM64);
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4, 4, true>), SM64);
+            hipLaunchKernelGGL((attn64_kernel<2, 33, 4, true>), dim3(grid64), dim3(256), SM64, stream, a);
+            hipLaunchKernelGGL((attn64_kernel<2, 4, 4, true>), dim3(grid64), dim3(256), SM64, stream, a);
+        } else {
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 33>), SM64);
+            PF_SET_MAX_LDS_ONCE((attn64_kernel<2, 4>), SM64);
+            hipLaunchKernelGGL((attn64_kernel<2, 33>), dim3(grid64), dim3(256), SM64, stream, a);
+            hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, stream, a);
+        }
         hipError_t e64 = hipGetLastError();
         if (e64 != hipSuccess) return pf_set_err(hipGetErrorString(e64));
         return 0;
     }
     const int grid = (a.nqt - a.qt0) * a.H * a.B;
     // one max chain, three waves per SIMD: 2 / 4 chains and 2 waves per SIMD measured within 2 % (same log)
-    if (!d->q_prescaled) hipLaunchKernelGGL((attn_kernel<false, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
+    if (vrow) {
+        if (!d->q_prescaled) hipLaunchKernelGGL((attn_kernel<false, 1, 3, true>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((attn_kernel<true, 1, 3, true>), dim3(grid), dim3(256), 0, stream, a);
+    } else if (!d->q_prescaled) hipLaunchKernelGGL((attn_kernel<false, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((attn_kernel<true, 1, 3>), dim3(grid), dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return pf_set_err(hipGetErrorString(e));

@@ -31,7 +31,9 @@
 // issue, not by the matrix pipe.
 // NW = waves per workgroup (4: 256 query rows, two workgroups per CU; 8: 512 rows, one workgroup per CU -- every K / V^T tile
 // then serves twice the rows: half the LDS-DMA pieces per wave and tile, whose issue costs a wave 100-150 cycles each).
-template <int OCC, int MODE = 0, int NW = 4>
+// VROW: V arrives token-major like K (no V^T image, no pf_v_transpose pass): the V tile is staged row-major and the PV
+// operand is read with the hardware transpose (attention.hip: vrow_fragment).
+template <int OCC, int MODE = 0, int NW = 4, bool VROW = false>
 __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     constexpr int ABL = MODE;
     constexpr bool FAST = (MODE & 1) != 0, FIXUP = (MODE & 4) != 0;
@@ -145,8 +147,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     // ---- DMA sources: wave owns pieces i = wid*2 + j (rows 8i..8i+7) of the K and V^T tiles.  Addresses are a wave-uniform
     //      tile base (scalar registers, advanced per tile) + one constant 32-bit byte offset per lane and piece
     const char* const kbase = (const char*)(p.K + (long long)b * p.sK + h * p.hs_qk);
-    const char* const vbase = (const char*)(p.Vt + (long long)b * p.sVb + (long long)h * p.sVh);
-    const int ldk2 = p.ldk * 2;
+    const char* const vbase = VROW ? (const char*)(p.V + (long long)b * p.sV + h * p.hs_v)
+                                   : (const char*)(p.Vt + (long long)b * p.sVb + (long long)h * p.sVh);
+    const int ldk2 = p.ldk * 2, ldv2 = p.ldv * 2;
     int prow[PJ];
     unsigned pc2[PJ], voff[PJ];
 #pragma unroll
@@ -154,15 +157,23 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
         const int i = wid * PJ + j;
         prow[j] = 8 * i + (lane >> 3);
         pc2[j] = (unsigned)(((lane & 7) ^ (((i & 1) << 2) + (lane >> 4))) * 16);
-        voff[j] = (unsigned)(prow[j] * p.Lp * 2) + pc2[j];
+        // V^T image: row = feature, keys along the row.  VROW: this lane's source chunk of key row prow[j]
+        voff[j] = VROW ? (unsigned)(((lane & 7) ^ (((prow[j] >> 1) & 1) << 2)) * 16) : (unsigned)(prow[j] * p.Lp * 2) + pc2[j];
     }
+    const unsigned vtr0 = vrow_lane_offset(lane, 0), vtr1 = vrow_lane_offset(lane, 1);
     auto issue_k = [&](int jt, int buf, int j) {
         const int last = p.L - 1 - jt * KB;                 // rows of the tile beyond the sequence re-read its last key
         const unsigned off = (unsigned)(min(prow[j], last) * ldk2) + pc2[j];
         glds16(kbase + (long long)jt * KB * ldk2 + off, smem + buf * ABUF + (wid * PJ + j) * 1024);
     };
     auto issue_v = [&](int jt, int buf, int j) {
-        glds16(vbase + (long long)jt * (KB * 2) + voff[j], smem + buf * ABUF + KTILE + (wid * PJ + j) * 1024);
+        if constexpr (VROW) {
+            const int last = p.L - 1 - jt * KB;             // keys beyond the sequence re-read the last one (their P is 0)
+            const unsigned off = (unsigned)(min(prow[j], last) * ldv2) + voff[j];
+            glds16(vbase + (long long)jt * KB * ldv2 + off, smem + buf * ABUF + KTILE + (wid * PJ + j) * 1024);
+        } else {
+            glds16(vbase + (long long)jt * (KB * 2) + voff[j], smem + buf * ABUF + KTILE + (wid * PJ + j) * 1024);
+        }
     };
     // the wave's own 64 query rows -> LDS, same 128-byte-row image and chunk swizzle as a K tile (piece k = rows 8k..8k+7:
     // lane -> row 8k + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ ((row >> 1) & 7)); only this wave reads them
@@ -211,9 +222,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     auto read_v = [&](int buf) {
         const char* sv = smem + buf * ABUF + KTILE;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (VROW) {
+                vf[0][g] = vrow_fragment(sv, vtr0, g);
+                vf[1][g] = vrow_fragment(sv, vtr1, g);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) vf[i][g] = *(const bf16x8_t*)(sv + i * 4096 + foff[g]);
+                for (int i = 0; i < 2; ++i) vf[i][g] = *(const bf16x8_t*)(sv + i * 4096 + foff[g]);
+            }
+        }
     };
     auto read_q = [&](int x, bf16x8_t* qf) {
         const char* s_ = sq + wid * QWAVE + x * 4096;

@@ -201,6 +201,7 @@ class FluxEngine(DeviceModuleAPI):
         self.overlap_text = True        # text stream of the double blocks on a side HIP stream
         self.skip_dead_rows = True      # last block: Q / MLP / attention / proj_out only for the current frame's rows
         self.fuse_qk = True             # QK-RMSNorm + RoPE inside the K|V|Q projections (pf_gemm_desc.qk_*); False = separate pass
+        self.v_rowmajor = True          # attention reads V token-major (hardware transpose read); False = pf_v_transpose + V^T image
         self._side = None
         # how the ~300 launches of the blocks + head of one forward reach the device (cmdlist.py):
         #   "eager": one ctypes call per launch;  "list": recorded once per plan, re-issued from C by one call;
@@ -328,7 +329,7 @@ class FluxEngine(DeviceModuleAPI):
             # structure, the row restriction of the last block, and the GEMM dispatch policy / split-K state in force
             # when the descriptors were recorded (pf_gemm_set_policy picks kernels at record time)
             key = (id(self), self._ws_gen, self.overlap_text, self.skip_dead_rows, self.launch_mode != "list",
-                   ops.POLICY_GEN, self.fuse_qk)
+                   ops.POLICY_GEN, self.fuse_qk, self.v_rowmajor)
             ent = getattr(plan, "_launch_list", None)
             if ent is not None and ent[0] == key:
                 break
@@ -382,7 +383,7 @@ class FluxEngine(DeviceModuleAPI):
         hidden = self._buf("hidden", B * L * d, torch.bfloat16)
         xn = self._buf("xn", B * L * d, torch.bfloat16)
         big = self._buf("big", B * L * 7 * d, torch.bfloat16)
-        vT = self._buf("vT", B * H * 64 * Lp, torch.bfloat16)
+        vT = None if self.v_rowmajor else self._buf("vT", B * H * 64 * Lp, torch.bfloat16)      # V^T image of the older V path only
         return w, d, H, B, Lt, L, L_img, Lp, hidden, xn, big, vT
 
     def _embed_tokens(self, plan, clips, ctx, shared_clips=False, debug=None):
@@ -498,9 +499,10 @@ class FluxEngine(DeviceModuleAPI):
             if not fuse:
                 ops.qk_norm_rope(big, 3 * d, L3, 2 * d, 0, blk["norm_q"], blk["norm_k"], blk["norm_added_q"],
                                  blk["norm_added_k"], plan.rope, B, L, Lt, H, q_scale=qs, eps=w.qk_eps)
-            ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
+            if not self.v_rowmajor:
+                ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
             ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
-                          q_row_begin=r0 if tail else 0)
+                          q_row_begin=r0 if tail else 0, v_off=d if self.v_rowmajor else None)
             join(0, 1)
             if not pre_only:
                 with on_side():
@@ -549,9 +551,10 @@ class FluxEngine(DeviceModuleAPI):
                 if not fuse:
                     ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H,
                                      q_scale=qs, eps=w.qk_eps)
-                ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
+                if not self.v_rowmajor:
+                    ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
                 ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
-                              q_row_begin=r0)
+                              q_row_begin=r0, v_off=d if self.v_rowmajor else None)
                 ops.gemm(big, blk["out"][0], hidden, n_cur, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
                          flags=GEMM_GATE_RES, a_off=r0 * 7 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, tail_workspace=ws_img)
@@ -563,8 +566,10 @@ class FluxEngine(DeviceModuleAPI):
                              q_col0=2 * d) if fuse else None)
             if not fuse:
                 ops.qk_norm_rope(big, 7 * d, L7, 2 * d, 0, blk["norm_q"], blk["norm_k"], None, None, plan.rope, B, L, Lt, H, q_scale=qs)
-            ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
-            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True)
+            if not self.v_rowmajor:
+                ops.v_transpose(big, vT, d, 7 * d, L7, B, H, L, Lp)
+            ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 7 * d, L7, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
+                          v_off=d if self.v_rowmajor else None)
             ops.gemm(big, blk["out"][0], hidden, L, d, 5 * d, 7 * d, 5 * d, d, bias=blk["out"][1], res=hidden,
                      gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L7, strideC=Ld, strideR=Ld, gate_stride=nm,
                      flags=GEMM_GATE_RES, a_off=2 * d, tail_workspace=ws_img)

@@ -99,7 +99,7 @@ class FluxEngineSP(FluxEngine):
             hidden=self._buf("sp_hidden", B * nloc * d, bf), xn=self._buf("sp_xn", B * nloc * d, bf),
             big=self._buf("sp_big", B * nloc * 7 * d, bf), send1=self._buf("sp_send1", B * nloc * 3 * d, bf),
             recv1=self._buf("sp_recv1", L * B * max(mc, 1), bf), obuf=self._buf("sp_obuf", L * B * max(mh, 1) * 64, bf),
-            recv2=self._buf("sp_recv2", B * nloc * d, bf), vT=self._buf("vT", B * max(mh, 1) * 64 * Lp, bf),
+            recv2=self._buf("sp_recv2", B * nloc * d, bf), vT=None,
             # scratch of the text rows' skinny GEMMs: same K split as the single-process engine (one 128-row tile per
             # prompt either way), hence the same fp32 summation order and bit-identical text rows
             ws_txt=self._buf("splitk_txt", 8 << 20, torch.float32),
@@ -169,10 +169,10 @@ class FluxEngineSP(FluxEngine):
             if mh:
                 ops.qk_norm_rope(recv1, B * mc, mc, 128, 0, *norms, plan.rope, B, L, Lt, mh, q_scale=qs,
                                  head_stride=lay.HEAD_COLS, eps=w.qk_eps)
-                ops.v_transpose(recv1, vT, 64, B * mc, mc, B, mh, L, Lp, head_stride=lay.HEAD_COLS)
-                ops.attention(recv1, recv1, vT, obuf, 128, 0, 0, B * mc, mc, B, mh, L, Lp, Lt, plan, scale,
+                # V = columns 64 .. 127 of every head's [k | v | q] block of the received matrix: read token-major
+                ops.attention(recv1, recv1, None, obuf, 128, 0, 0, B * mc, mc, B, mh, L, Lp, Lt, plan, scale,
                               q_prescaled=True, head_stride_qk=lay.HEAD_COLS, ldo=B * mh * 64, o_bstride=mh * 64,
-                              q_row_begin=q_row_begin)
+                              q_row_begin=q_row_begin, v_off=64)
 
         n_dbl = len(w.dbl)
         for bi, blk in enumerate(w.dbl):

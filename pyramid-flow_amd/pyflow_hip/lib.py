@@ -50,7 +50,8 @@ class AttnDesc(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("L", C.c_int), ("Lp", C.c_int), ("Lt", C.c_int),
                 ("a_lo", C.c_void_p), ("a_hi", C.c_void_p), ("b_hi", C.c_void_p), ("tile_kv_end", C.c_void_p),
                 ("scale", C.c_float), ("head_stride_qk", C.c_int), ("q_row_begin", C.c_int), ("q_prescaled", C.c_int),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
+                ("V", C.c_void_p), ("ldv", C.c_int), ("strideV", C.c_longlong)]
 
 
 class AttnSmallDesc(C.Structure):

@@ -126,16 +126,21 @@ def _attention_workspace(device, nbytes):
 
 
 def attention(Q, K, Vt, O, q_off, k_off, o_off, ld, bstride, B, H, Lseq, Lp, Lt, plan, scale, q_prescaled=False,
-              head_stride_qk=0, ldo=None, o_bstride=None, q_row_begin=0):
+              head_stride_qk=0, ldo=None, o_bstride=None, q_row_begin=0, v_off=None):
+    """v_off (elements): V is a column block of the K buffer (token-major, same leading dimension, batch and head strides) and
+    the kernels transpose it on the way out of LDS -- no pf_v_transpose pass, `Vt` may be None.  v_off=None: `Vt` is the
+    V^T image written by v_transpose."""
     lib = L.load()
     d = AttnDesc()
+    if v_off is not None:
+        d.V, d.ldv, d.strideV = K.data_ptr() + 2 * v_off, ld, bstride
     if q_prescaled:
         need = int(lib.pf_attention_workspace_bytes(C.c_int(B), C.c_int(H), C.c_int(Lseq)))
         ws = _attention_workspace(Q.device, need)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     d.Q = Q.data_ptr() + 2 * q_off
     d.K = K.data_ptr() + 2 * k_off
-    d.Vt = Vt.data_ptr()
+    d.Vt = Vt.data_ptr() if Vt is not None else None
     d.O = O.data_ptr() + 2 * o_off
     d.ldq = d.ldk = ld
     d.ldo = ld if ldo is None else ldo

@@ -64,7 +64,8 @@ def main():
         x = v.cpu()[:, :, :eng.w.out_cols].reshape(2, tcur, hcur // 2, wcur // 2, 2, 2, Cc)
         x = x.permute(0, 1, 2, 4, 3, 5, 6).reshape(2, tcur, hcur, wcur, Cc).permute(0, 4, 1, 2, 3)
         err_oracle = rel_l2(x, o_ref)
-        ok = err < 2e-3 and err_oracle < 2e-2
+        # (vs the single-rank engine: two bf16 evaluations whose small GEMMs split K differently since round 4)
+        ok = err < 5e-3 and err_oracle < 2e-2
         with open(out_path, "w") as f:
             f.write(f"vs single-rank HIP {err:.3e}, vs oracle {err_oracle:.3e} {int(ok)} world={world} heads={heads} "
                     f"lay_rows={eng.layout(plan).rows} lay_heads={eng.layout(plan).heads}\n")

@@ -54,7 +54,8 @@ def _run(qkv, plan, B, L, Lp, q_row_begin=0):
 def _which(plan, B, L, Lp, prescaled=True):
     from pyflow_hip import lib, ops
     d = lib.AttnDesc()
-    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 16)
+    need = int(lib.load().pf_attention_workspace_bytes(C.c_int(B), C.c_int(H), C.c_int(L)))
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), need)
     d.Q = d.K = d.Vt = ws.data_ptr()
     d.O = ws.data_ptr() + (1 << 40)               # an output range that does not touch Q (pf_attention_which only compares addresses)
     d.ldq = d.ldk = 3 * D
@@ -190,7 +191,8 @@ def test_pair_is_not_chosen_for_a_partial_overlap_of_output_and_q():
     B = 2
     plan = SequencePlan(CLIPS, _mask(), [16, 24, 24], DEV)
     L, Lp = plan.L, plan.Lp
-    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 16)
+    need = int(lib.load().pf_attention_workspace_bytes(C.c_int(B), C.c_int(H), C.c_int(L)))
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), need)
     buf = torch.empty(B, L, 3 * D, dtype=torch.bfloat16, device=DEV)
     d = lib.AttnDesc()
     d.K = d.Vt = buf.data_ptr()
@@ -304,3 +306,53 @@ def test_kv_split_pair_rank_shape_at_the_headline_length():
     assert wt > 64                                         # 16 query tiles x 8 = 128 workgroups -> 4 parts
     assert (tail[:, :r0].float() == 7.0).all()
     assert rel_l2(tail[:, r0:].float().cpu(), out[:, r0:].float().cpu()) < 2e-3      # other part boundaries: fp32 summation order
+
+
+# ---- V token-major (ABI 4: pf_attn_desc.V): the kernels transpose V on the way out of LDS (ds_read_b64_tr_b16) ------------------
+@pytest.mark.parametrize("Hh,clips,expect", [(30, CLIPS, 64), (6, CLIPS, 68), (2, [(1, 24, 40), (1, 24, 40)], 32)])
+def test_row_major_v_equals_the_transposed_image_path(Hh, clips, expect):
+    """the same attention with V read token-major (no pf_v_transpose pass) and with the V^T image: every kernel form -- the
+    pair, the KV-split pair, the 128-row kernel -- must give the SAME BITS (same values into the same MFMAs in the same
+    order; only the route of V through LDS differs), plus the dense fp32 reference for the small case"""
+    from pyflow_hip import lib, ops
+    plan, qkv, B, Dh, L, Lp = _few_heads_case(Hh, clips, "mixed" if L_ok(clips) else "benign", 21)
+    out_t, which = _attend(qkv, plan, B, Hh, Dh, L, Lp)
+    assert which == expect
+    out_r = torch.zeros_like(out_t)
+    d = lib.AttnDesc()
+    d.Q, d.K, d.O = qkv.data_ptr() + 2 * 2 * Dh, qkv.data_ptr(), out_r.data_ptr()
+    d.V, d.ldv, d.strideV = qkv.data_ptr() + 2 * Dh, 3 * Dh, L * 3 * Dh
+    d.ldq = d.ldk = 3 * Dh
+    d.ldo = Dh
+    d.strideQ = d.strideK = L * 3 * Dh
+    d.strideO = L * Dh
+    d.B, d.H, d.L, d.Lp, d.Lt = B, Hh, L, Lp, LT
+    d.a_lo, d.a_hi, d.b_hi = plan.a_lo.data_ptr(), plan.a_hi.data_ptr(), plan.b_hi.data_ptr()
+    d.tile_kv_end = plan.tile_kv_end.data_ptr()
+    d.scale, d.q_prescaled = 0.125, 1
+    need = int(lib.load().pf_attention_workspace_bytes(C.c_int(B), C.c_int(Hh), C.c_int(L)))
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), need)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert lib.load().pf_attention_which(C.byref(d)) == expect
+    lib.check(lib.load().pf_attention_bf16(C.byref(d), lib.stream()))
+    assert torch.isfinite(out_r.float()).all()
+    assert torch.equal(out_r, out_t), f"row-major V differs from the V^T path: rel {rel_l2(out_r.float().cpu(), out_t.float().cpu()):.3e}"
+    if L <= 1024:
+        ref = _dense_ref(qkv, plan, B, Hh, Dh, L, list(range(L)))
+        assert rel_l2(out_r.float().cpu(), ref.cpu()) < 1e-2
+    # not pre-scaled (the 128-row kernel's other instantiation)
+    d.q_prescaled, d.workspace, d.workspace_bytes = 0, None, 0
+    a = torch.zeros_like(out_t)
+    d.O = a.data_ptr()
+    lib.check(lib.load().pf_attention_bf16(C.byref(d), lib.stream()))
+    vT = torch.zeros(B, Hh, 64, Lp, dtype=torch.bfloat16, device=DEV)
+    ops.v_transpose(qkv, vT, Dh, 3 * Dh, L * 3 * Dh, B, Hh, L, Lp)
+    d.V, d.Vt, d.strideVt_b, d.strideVt_h = None, vT.data_ptr(), Hh * 64 * Lp, 64 * Lp
+    b_ = torch.zeros_like(out_t)
+    d.O = b_.data_ptr()
+    lib.check(lib.load().pf_attention_bf16(C.byref(d), lib.stream()))
+    assert torch.equal(a, b_)
+
+
+def L_ok(clips):
+    return sum(c[0] * (c[1] // 2) * (c[2] // 2) for c in clips) + LT >= 3008

@@ -189,7 +189,9 @@ def test_full_size_forward_vs_oracle_one_block_of_each_kind():
     so.pf_gemm_workspace_bytes.restype = C.c_longlong
     assert so.pf_gemm_workspace_bytes(C.c_int(15488), C.c_int(2), C.c_int(D), C.c_int(5 * D)) > 0
     ad = lib.AttnDesc()
-    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()), 1 << 20)
+    so.pf_attention_workspace_bytes.restype = C.c_longlong
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()),
+                                  int(so.pf_attention_workspace_bytes(C.c_int(2), C.c_int(H), C.c_int(15488))))
     ad.Q = ad.O = ws.data_ptr()
     ad.K = ad.Vt = ws.data_ptr()
     ad.ldq = ad.ldk = ad.ldo = 7 * D
@@ -198,7 +200,7 @@ def test_full_size_forward_vs_oracle_one_block_of_each_kind():
     ad.workspace, ad.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     assert so.pf_attention_which(C.byref(ad)) == 64              # the in-place form of the single blocks
     ad.q_row_begin = plan.L - plan.n_cur
-    assert so.pf_attention_which(C.byref(ad)) == 64              # ... and of the last block's restricted rows
+    assert so.pf_attention_which(C.byref(ad)) == 64              # ... and of the last block's restricted rows (16 tiles x 60 workgroups)
     clips_d = [c.cuda() for c in clips]
     ctx = eng.encode_context(enc)
     dbg = {}

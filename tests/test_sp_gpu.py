@@ -41,7 +41,12 @@ def test_sp_engine_single_rank_matches_plain_engine(heads):
     b.encode_context(enc)
     va = a.forward_tokens(plan, clips, [704.0, 704.0], pooled).clone()
     vb = b.forward_tokens(plan, clips, [704.0, 704.0], pooled).clone()
-    assert rel_l2(vb.cpu(), va.cpu()) < 2e-3
+    # two bf16 evaluations of one forward: the engines' GEMMs differ in column layout and, since round 4, in where the
+    # sequence-parallel engine's small image GEMMs split K (fp32 summation order); measured 1.3e-3 / 2.7e-3
+    assert rel_l2(vb.cpu(), va.cpu()) < 5e-3
+    b.split_small = False
+    vc = b.forward_tokens(plan, clips, [704.0, 704.0], pooled).clone()
+    assert rel_l2(vc.cpu(), va.cpu()) < 2e-3
 
 
 @pytest.mark.parametrize("variant", ["flux", "mmdit"])
