@@ -77,6 +77,7 @@ constexpr int HALO_PIECES = (HALO_CHUNKS + 63) / 64;      // 39 one-KiB pieces (
 constexpr int HALO_BYTES = 40 * 1024;            // buffer size (>= 39 KiB: the partial piece spills into the pad)
 constexpr int WS_BYTES = 128 * 64;               // one (tap, quarter) filter slice
 constexpr int SMEM = 2 * HALO_BYTES + 4 * WS_BYTES;       // 112 KiB
+constexpr int SMEM_T2 = 2 * HALO_BYTES + 8 * WS_BYTES;    // 144 KiB (two taps per step)
 constexpr int NSTAGE = 12, NSTEP = NSTAGE * 9;   // (dt, quarter) stages x 9 spatial taps
 
 // pieces a wave issues per step, in program order: [filter piece of step s + 3][halo piece k * 8 + wid of the next stage, k < 5]
@@ -265,6 +266,209 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     }
 }
 
+template <int SKEW>
+__global__ __launch_bounds__(512, 2) void conv_halo128_t2_kernel(const HArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const s_halo = smem;                       // 2 buffers
+    char* const s_w = smem + 2 * HALO_BYTES;         // 8 slots (two taps per step, slices two steps ahead)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = SKEW ? (wid >> 2) : 0;           // wave group (SKEW): group 1 runs one barrier behind group 0
+    const int wm = wid & 3, wn = wid >> 2;           // wave tile: patch rows 4 wm .. +4 (128 pixels), filters 64 wn .. +64
+    // (with SKEW the two waves of a SIMD are wid and wid + 4 = the two filter halves of the same pixel rows)
+
+    // ---- tile
+    const int tiles_x = p.Wd / PW, tiles_y = p.H / PH;
+    int tile = blockIdx.x;
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int ty = tile % tiles_y; const int t = tile / tiles_y;
+    const int y0 = ty * PH, x0 = tx * PW;
+
+    // ---- DMA geometry of the halo: piece pc covers LDS chunks [64 pc, 64 pc + 64); chunk g = 4 * halo pixel + slot
+    // this wave's pieces of a stage: pc = k * 8 + wid for k = 0..4 (wave 7's k = 4 piece would be pc 39: it re-issues 38)
+    unsigned hsrc[5];                                // byte offset of this lane's source chunk relative to the halo origin
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int pc = k * 8 + wid;
+        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
+        int g = pc * 64 + lane;
+        g = g < HALO_CHUNKS ? g : HALO_CHUNKS - 1;   // the partial piece: lanes past the end re-read the last chunk (lands in the pad)
+        const int hp = g >> 2, slot = g & 3;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int c = slot ^ ((hx >> 2) & 3);        // the chunk that belongs in this slot
+        hsrc[k] = (unsigned)((hy * p.Wp + hx) * 256 + c * 16);
+    }
+    // filter slice: 8 pieces, wave wid owns LDS rows 16 wid .. +16; LDS row r = 64 wn' + 16 j + i holds filter
+    // 64 wn' + 32 (j >> 1) + 8 (i >> 2) + 4 (j & 1) + (i & 3)      (gemm8p.hip's permutation: epilogue from registers)
+    unsigned wsrc;
+    {
+        const int r = 16 * wid + (lane >> 2), slot = lane & 3;
+        const int wn_ = r >> 6, j = (r >> 4) & 3, i = r & 15;
+        const int n = 64 * wn_ + 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3);
+        const int c = slot ^ ((r >> 2) & 3);
+        wsrc = (unsigned)(n * (27 * 256) + c * 16);
+    }
+    const char* const Xb = (const char*)(p.X + p.in_base_off) + ((long long)t * p.Hp * p.Wp + (long long)y0 * p.Wp + x0) * 256;
+    const char* const Wb = (const char*)p.W;
+
+    auto issue_halo = [&](int stage, int k) {        // piece k of this wave for (dt, q) = (stage / 4, stage % 4)
+        const int dt = stage >> 2, q = stage & 3;
+        const char* src = Xb + (long long)dt * p.Hp * p.Wp * 256 + q * 64;
+        int pc = k * 8 + wid;
+        pc = pc < HALO_PIECES ? pc : HALO_PIECES - 1;
+        glds16(src + hsrc[k], s_halo + (stage & 1) * HALO_BYTES + pc * 1024);
+    };
+    auto issue_w = [&](int step) {                   // this wave's piece of the filter slice of `step`
+        const int stage = step / 9, k = step - stage * 9;
+        const int dt = stage >> 2, q = stage & 3;
+        const int tap = dt * 9 + k;
+        glds16(Wb + tap * 256 + q * 64 + wsrc, s_w + (step & 7) * WS_BYTES + wid * 1024);
+    };
+
+    // ---- fragment read offsets (bytes)
+    const int fi = lane & 15, fc = lane >> 4;
+    unsigned xoff[3][2];                             // [dw][x half]: column part of the halo address incl. the swizzled chunk
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+        for (int xh = 0; xh < 2; ++xh) {
+            const int hx = 16 * xh + fi + dw;
+            xoff[dw][xh] = (unsigned)(hx * 64 + ((fc ^ ((hx >> 2) & 3)) << 4));
+        }
+    const unsigned woff = (unsigned)((64 * wn + fi) * 64 + ((fc ^ ((fi >> 2) & 3)) << 4));   // + 16 j rows
+
+    f32x4_t acc[8][4];                               // [pixel fragment f: patch row 4 wm + (f >> 1), x half f & 1][filter fragment j]
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[f][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fx[8], fw[2][4];        // pixel fragments shared by the two taps of a step (the second tap's are read during the first's MFMAs)
+
+    auto read_w = [&](int u, int step) {
+        const char* wb = s_w + (step & 7) * WS_BYTES + woff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fw[u][j] = *(const bf16x8_t*)(wb + j * (16 * 64));
+    };
+    auto read_x = [&](int stage, int k, int f0) {                     // pixel fragments f0 .. f0 + 3 of tap k
+        const int dh = k / 3, dw = k - dh * 3;
+        const char* hb = s_halo + (stage & 1) * HALO_BYTES;
+#pragma unroll
+        for (int f = f0; f < f0 + 4; ++f) {
+            const int hy = 4 * wm + (f >> 1) + dh;
+            fx[f] = *(const bf16x8_t*)(hb + hy * (HW * 64) + (dw == 0 ? xoff[0][f & 1] : (dw == 1 ? xoff[1][f & 1] : xoff[2][f & 1])));
+        }
+    };
+    auto mfmas = [&](int u, int f0) {                                 // 16 MFMAs: pixel fragments f0 .. f0 + 3 x 4 filter fragments
+#pragma unroll
+        for (int f = f0; f < f0 + 4; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][j], fx[f], acc[f][j], 0, 0, 0);
+    };
+
+    // ---- two taps per step: the nine taps of a stage run as steps j = 0..4 = taps (0,1) (2,3) (4,5) (6,7) (8): half the
+    // barriers per MFMA.  `step` below counts TAPS (ring slot = tap index & 7).  In program order a wave issues per step
+    // [filter pieces of the taps of step j + 2][halo pieces of the next stage: 2, 2, 1, 0, 0]; before step j + 1 is read,
+    // everything up to the filter pieces of step j + 1 must have landed: allowed outstanding = h(j-1) + f(j) + h(j).
+    auto ntap = [](int j) { return j == 4 ? 1 : 2; };
+    auto tap_of = [&](int stage, int j) { return stage * 9 + 2 * j; };
+    auto issue_w_step = [&](int stage, int j) {              // filter pieces of step (stage, j), normalised over stage ends
+        if (j >= 5) { j -= 5; ++stage; }
+        if (stage >= NSTAGE) return;
+        const int t0 = tap_of(stage, j);
+        issue_w(t0);
+        if (j < 4) issue_w(t0 + 1);
+    };
+    // prologue: halo of stage 0, filter pieces of steps 0 and 1; then: halo 0 + the slices of step 0 landed
+#pragma unroll
+    for (int k = 0; k < 5; ++k) issue_halo(0, k);
+    issue_w_step(0, 0);
+    issue_w_step(0, 1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    BAR();
+    if (SKEW && grp == 1) BAR();
+    for (int stage = 0; stage < NSTAGE; ++stage) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int t0 = tap_of(stage, j);
+            // R slot
+            issue_w_step(stage, j + 2);
+            if (stage + 1 < NSTAGE) {
+                if (j == 0) { issue_halo(stage + 1, 0); issue_halo(stage + 1, 1); }
+                if (j == 1) { issue_halo(stage + 1, 2); issue_halo(stage + 1, 3); }
+                if (j == 2) issue_halo(stage + 1, 4);
+            }
+            read_w(0, t0);
+            read_x(stage, 2 * j, 0);
+            read_x(stage, 2 * j, 4);
+            if (j < 4) read_w(1, t0 + 1);
+            const bool last_stages = stage >= NSTAGE - 2;    // fewer pieces are issued near the end: drain completely there
+            auto counted_wait = [&]() {
+                if (last_stages) { vmwait<0>(); return; }
+                switch (j) {                                  // h(j-1) + f(j) + h(j), f(j) = taps of step j + 2
+                    case 0: vmwait<0 + 2 + 2>(); break;
+                    case 1: vmwait<2 + 2 + 2>(); break;
+                    case 2: vmwait<2 + 1 + 1>(); break;
+                    case 3: vmwait<1 + 2 + 0>(); break;
+                    default: vmwait<0 + 2 + 0>(); break;
+                }
+            };
+            if (SKEW && grp == 1) counted_wait();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BAR();
+            // M slot
+            // first tap; the second tap's pixel fragments replace the first's as soon as their MFMAs have issued and land
+            // under the MFMAs that follow (reads only: no LDS hazard with the other group's R slot)
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(0, 0);
+            FENCE();
+            if (j < 4) read_x(stage, 2 * j + 1, 0);
+            FENCE();
+            mfmas(0, 4);
+            FENCE();
+            if (j < 4) {
+                read_x(stage, 2 * j + 1, 4);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                FENCE();
+                mfmas(1, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                FENCE();
+                mfmas(1, 4);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (!(SKEW && grp == 1)) counted_wait();
+            BAR();
+        }
+    }
+    if (SKEW && grp == 0) BAR();
+
+    // ---- epilogue from registers: lane (fi = pixel in fragment, fc) owns filters 64 wn + 32 hsel + 8 fc + (0..7) of pixel
+    // (patch row 4 wm + (f >> 1), x = 16 (f & 1) + fi) in acc[f][2 hsel] | acc[f][2 hsel + 1]
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        const int n = 64 * wn + 32 * hsel + 8 * fc;
+        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int y = y0 + 4 * wm + (f >> 1), x = x0 + 16 * (f & 1) + fi;
+            const long long off = p.out_base_off + (((long long)t * p.Hop + y) * p.Wop + x) * 128 + n;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[f][2 * hsel][r] + b0[r]; v[4 + r] = acc[f][2 * hsel + 1][r] + b1[r]; }
+            if (p.res) {
+                const u32x4_t rr = *(const u32x4_t*)(p.res + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += __uint_as_float(rr[e] << 16);
+                    v[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                }
+            }
+            const u32x4_t o = (u32x4_t){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            *(u32x4_t*)(p.Y + off) = o;
+        }
+    }
+}
+
 // ---- reference: one thread per (pixel, filter), fp32 accumulation in tap-major order
 __global__ void naive_conv(const HArgs p, float* out) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,6 +506,23 @@ static float run_halo(const HArgs& a, int iters) {
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(conv_halo128_kernel<SKEW>, dim3(grid), dim3(512), SMEM, 0, a);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+static float run_halo_t2(const HArgs& a, int iters) {
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute((const void*)conv_halo128_t2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_T2)); set = true; }
+    const int grid = a.T * (a.H / PH) * (a.Wd / PW);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(conv_halo128_t2_kernel<1>, dim3(grid), dim3(512), SMEM_T2, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(conv_halo128_t2_kernel<1>, dim3(grid), dim3(512), SMEM_T2, 0, a);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -365,6 +586,12 @@ int main(int argc, char** argv) {
         const float ms = skew ? run_halo<1>(a, 10) : run_halo<0>(a, 10);
         printf("conv_halo128_kernel<SKEW=%d>  T=%d %dx%d res=%d: %.3f ms  %.0f TFLOP/s\n", skew, T, H, Wd, with_res, ms, flops / ms / 1e9);
         check(skew ? "halo kernel, two wave groups" : "halo kernel, plain", dY);
+    }
+    {
+        CK(hipMemset(dY, 0, ny * 2));
+        const float ms = run_halo_t2(a, 10);
+        printf("conv_halo128_t2_kernel<SKEW=1> (two taps per step)  T=%d %dx%d res=%d: %.3f ms  %.0f TFLOP/s\n", T, H, Wd, with_res, ms, flops / ms / 1e9);
+        check("halo kernel, two taps per step", dY);
     }
     // the shipped library on the same problem
     void* lib = dlopen("pyramid-flow_amd/libpyflow_hip.so", RTLD_NOW);
