@@ -37,8 +37,8 @@ WORKLOADS = {
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E (same guide)
-PMC_PROFILE = "r03_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the DiT kernels' `traffic` fields are replayed from
-PMC_PROFILE_VAE = "r03_pmc_vae_tile.json"      # ... and the VAE kernels' (one tile-chunk window at the timed launch shapes)
+PMC_PROFILE = "r04_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the DiT kernels' `traffic` fields are replayed from
+PMC_PROFILE_VAE = "r04_pmc_vae_tile.json"      # ... and the VAE kernels' (one tile-chunk window at the timed launch shapes)
 
 
 def build_pipeline(device, tiny=False, mmdit=False, stages=None):
@@ -562,12 +562,17 @@ def main():
                 if name[7:].split("<")[0] in n and ("true" in n or "conv_" in n):
                     return round(v["hbm_bytes_per_launch"])
             return None
-        key = {"attention": "attn64_kernel<2, ", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
+        # ("attention" = the fast pass of the pair: attn64_kernel<2, 33, 4, true> since round 4, <2, 1> in the round-3 profile)
+        key = {"attention": "attn64_kernel<2, 33", "gemm_kernel(128x128)": "gemm_kernel<false>"}.get(name, name)
         key = key.replace("gemm256_kernel<128>", "gemm256_kernel<128, false").replace("gemm256_kernel<192>", "gemm256_kernel<192, false") \
                  .replace("gemm256_kernel<256>", "gemm256_kernel<256, false")
         for n, v in pm.items():
             if key in n:
                 return round(v["hbm_bytes_per_launch"])
+        if name == "attention":
+            for n, v in pm.items():
+                if "attn64_kernel<2, 1" in n:
+                    return round(v["hbm_bytes_per_launch"])
         return None
     for r in list(extra.values()):
         if r is not None and r.get("traffic") is None:
