@@ -80,6 +80,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     const int tiles_x = p.Wd / PW, tiles_y = p.H / PH;
     int tile = blockIdx.x;
     const int nblk = blockIdx.y;                     // block of 128 filters (N = 128 gridDim.y)
+    // XCD-aware order (block b runs on XCD b % 8, each XCD has its own L2): an output frame's patch reads the input frames
+    // t, t + 1, t + 2, so the SAME patch of consecutive frames shares two of its three halos -- XCD x owns the patches
+    // x, x + 8, ... and its workgroups walk a patch's frames consecutively, which turns the temporal re-fetch into L2 hits
+    // (profiles/r04_pmc_vae_tile.json before this order: 5.6 bytes fetched per byte written on the 128 -> 128 layers)
+    const int npatch = tiles_x * tiles_y;
+    if ((npatch & 7) == 0) {
+        const int xcd = tile & 7, i = tile >> 3;
+        const int pl = i / p.T;
+        tile = (i - pl * p.T) * npatch + pl * 8 + xcd;            // (frame, patch) in the plain order below
+    }
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int ty = tile % tiles_y; const int t = tile / tiles_y;
     const int y0 = ty * PH, x0 = tx * PW;
