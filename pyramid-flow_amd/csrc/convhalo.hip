@@ -41,7 +41,9 @@ DEV unsigned pack2_rne(float a, float b) {
 struct HArgs {
     const bf16_bits* X; const bf16_bits* W; const float* bias; const bf16_bits* res; bf16_bits* Y;
     int T, H, Wd, Hp, Wp, Hop, Wop, Cout_pitch;
-    int cin;                 // input channels = pitch of X and of a filter tap (128 or 256)
+    int cin;                 // input channels = pitch of X and of a filter tap (128 / 256 / 512)
+    int st, sh, sw, Cg, t_shift;   // output map of the upsamplers: column n = g Cg + c, g = (pt sh + ph) sw + pw -> pixel-shuffle /
+                             //   depth-to-time placement (modeling_resnet.py:609-617, 716-729); 1, 1, 1, N, 0 = plain
     long long in_base_off, out_base_off;
     double* gn_stats;        // [frame][gn_C][2] (sum, sum of squares) of the stored output, or nullptr (pf_conv_desc.gn_stats)
     int gn_C;
@@ -241,13 +243,20 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     for (int hsel = 0; hsel < 2; ++hsel) {
         const int n = 128 * nblk + 64 * wn + 32 * hsel + 8 * fc;
         const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
+        // output placement of this lane's 8 filters (one group: Cg % 8 == 0): frame t st + pt (+ t_shift; < 0 = dropped),
+        // pixel (y sh + ph, x sw + pw), channel cc
+        const int gg = n / p.Cg, cc = n - gg * p.Cg;
+        const int shw = p.sh * p.sw;
+        const int pt = gg / shw, g2 = gg - pt * shw;
+        const int ph = g2 / p.sw, pw = g2 - ph * p.sw;
+        const int tf = t * p.st + pt + p.t_shift;
         float gs[8], gq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             const int y = y0 + 4 * wm + (f >> 1), x = x0 + 16 * (f & 1) + fi;
-            const long long off = p.out_base_off + (((long long)t * p.Hop + y) * p.Wop + x) * p.Cout_pitch + n;
+            const long long off = p.out_base_off + (((long long)(tf < 0 ? 0 : tf) * p.Hop + (y * p.sh + ph)) * p.Wop + (x * p.sw + pw)) * p.Cout_pitch + cc;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[f][2 * hsel][r] + b0[r]; v[4 + r] = acc[f][2 * hsel + 1][r] + b1[r]; }
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
                 }
             }
             const u32x4_t o = (u32x4_t){pack2_rne(v[0], v[1]), pack2_rne(v[2], v[3]), pack2_rne(v[4], v[5]), pack2_rne(v[6], v[7])};
-            *(u32x4_t*)(p.Y + off) = o;
+            if (tf >= 0) *(u32x4_t*)(p.Y + off) = o;
             if (do_stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -307,10 +316,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
 bool pf_conv_halo_supports(const pf_conv_desc* d, bool wide) {
     if (d->kt != 3 || d->kh != 3 || d->kw != 3 || (d->Cin != 128 && d->Cin != 256 && d->Cin != 512) || !d->bias) return false;
     if (d->N % 128 || d->N <= 0 || (!wide && (d->N != 128 || d->Cin == 512))) return false;
-    if ((d->n_valid > 0 ? d->n_valid : d->N) != d->N || d->Cg != d->N || d->Cout_pitch % 8) return false;
+    if ((d->n_valid > 0 ? d->n_valid : d->N) != d->N || d->Cout_pitch % 8 || d->Cg <= 0 || d->Cg % 8) return false;
+    const bool plain = d->st == 1 && d->sh == 1 && d->sw == 1 && d->out_t_shift == 0;
+    if (plain ? d->Cg != d->N : (!wide || d->N != d->st * d->sh * d->sw * d->Cg || (d->flags & PF_GEMM_GATE_RES))) return false;
     // a launch of at least half a round of the chip (the small 32 x 32 / 64 x 64-pixel layers stay with the implicit GEMM)
     if (d->N > 128 && (long long)d->T * (d->H / 16) * (d->W_ / 32) * (d->N / 128) < 128) return false;
-    if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->out_t_shift != 0) return false;
+    if (d->st < 1 || d->sh < 1 || d->sw < 1) return false;
     if ((d->in_sh > 1) || (d->in_sw > 1) || (d->in_st > 1)) return false;
     if (d->H % 16 || d->W_ % 32 || d->T <= 0) return false;
     if ((d->flags & ~PF_GEMM_GATE_RES) || (d->out_scale != 0.f && d->out_scale != 1.f)) return false;
@@ -328,6 +339,7 @@ int pf_conv_halo_launch(const pf_conv_desc* d, double* gn_stats, int gn_C, hipSt
     a.T = d->T; a.H = d->H; a.Wd = d->W_; a.Hp = d->Hp; a.Wp = d->Wp; a.Hop = d->Hop; a.Wop = d->Wop;
     a.Cout_pitch = d->Cout_pitch;
     a.cin = d->Cin;
+    a.st = d->st; a.sh = d->sh; a.sw = d->sw; a.Cg = d->Cg; a.t_shift = d->out_t_shift;
     a.in_base_off = d->in_base_off; a.out_base_off = d->out_base_off;
     a.gn_stats = gn_stats; a.gn_C = gn_C;
     const int grid = d->T * (d->H / PH) * (d->W_ / PW);

@@ -16,7 +16,7 @@ from util import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-def _desc_route(src, dst, cw, T, res=None):
+def _desc_route(src, dst, cw, T, res=None, st=1, sh=1, sw=1, t_shift=0):
     from pyflow_hip import lib as L_
     from pyflow_hip.lib import ConvDesc, GEMM_GATE_RES
     d = ConvDesc()
@@ -26,7 +26,7 @@ def _desc_route(src, dst, cw, T, res=None):
     d.Hp, d.Wp, d.Cin = src.Hp, src.Wp, src.Cp
     d.kt, d.kh, d.kw = cw.kt, cw.kh, cw.kw
     d.N, d.n_valid = cw.N, cw.n_valid
-    d.st = d.sh = d.sw = 1
+    d.st, d.sh, d.sw, d.out_t_shift = st, sh, sw, t_shift
     d.Cg = cw.Cg
     d.Hop, d.Wop, d.Cout_pitch = dst.Hp, dst.Wp, dst.Cp
     d.flags = GEMM_GATE_RES if res is not None else 0
@@ -109,3 +109,44 @@ def test_halo_route_only_where_the_kernel_applies():
     assert route(256, 256, 128, 128) == -2          # the 256-filter resnets at 128 x 128
     assert route(384, 128, 64, 64) != -2            # other input widths
     assert route(128, 128, 64, 64, k=1) != -2       # 1 x 1 x 1 shortcut convs
+
+
+@pytest.mark.parametrize("kind,Ci,Cg,T,H,W", [("spatial", 256, 256, 4, 64, 64), ("temporal", 256, 256, 4, 64, 64),
+                                             ("temporal_first", 128, 128, 4, 64, 128)])
+def test_halo_conv_upsampler_output_maps_equal_the_implicit_gemm(kind, Ci, Cg, T, H, W):
+    """the decoder's upsampler convs (N = 4 Cg / 2 Cg filters; pixel shuffle modeling_resnet.py:609-617, depth-to-time
+    :716-729 with the first-frame drop) through the halo kernel's epilogue placement: same values in the same places as the
+    implicit GEMM (whose placement the decode tests pin to the oracle), nothing written outside them"""
+    from pyflow_hip import ops
+    from pyflow_hip.vae import PBuf, ConvW, conv
+    g = torch.Generator().manual_seed(5)
+    groups = 4 if kind == "spatial" else 2
+    co = groups * Cg
+    x = torch.randn(T + 2, H, W, Ci, generator=g).to(torch.bfloat16)
+    w = (torch.randn(co, Ci, 3, 3, 3, generator=g) * 0.03)
+    b = torch.randn(co, generator=g)
+    src = PBuf("x", T, H, W, Ci, "cuda")
+    src.t.view(T + 2, H + 2, W + 2, src.Cp)[:, 1:-1, 1:-1, :Ci] = x.cuda()
+    src.cur = T
+    cw = ConvW(w, b, "cuda", groups)
+    outs = {}
+    for halo in (True, False):
+        ops.gemm_set_policy(5 if halo else -5)
+        try:
+            if kind == "spatial":
+                dst = PBuf("y", T, 2 * H, 2 * W, Cg, "cuda")
+                assert (_desc_route(src, dst, cw, T, sh=2, sw=2) == -2) == halo
+                conv(src, dst, cw, T, sh=2, sw=2)
+            else:
+                dst = PBuf("y", 2 * T, H, W, Cg, "cuda")
+                ts = -1 if kind == "temporal_first" else 0
+                assert (_desc_route(src, dst, cw, T, st=2, t_shift=ts) == -2) == halo
+                conv(src, dst, cw, T, st=2, t_shift=ts)
+            outs[halo] = dst.t.clone()
+        finally:
+            ops.gemm_set_policy(5)
+    assert outs[True].abs().max() > 0
+    d = (outs[True].float() - outs[False].float()).abs().max().item()
+    assert rel_l2(outs[True].float().cpu(), outs[False].float().cpu()) < 3e-3 and d <= 2 ** -5 * outs[False].float().abs().max().item()
+    # exactly the same set of elements was written (borders, cache slots, a dropped first frame stay zero in both)
+    assert torch.equal(outs[True] != 0, outs[False] != 0)
