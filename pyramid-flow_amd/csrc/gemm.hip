@@ -281,6 +281,7 @@ static int gemm256_force() { return g_gemm256_force; }
 static int g_gemm8p_mode = 0;
 static bool g_narrow_enabled = true;         // pf_gemm_set_policy(-3) / (3): never / again the narrow-N conv kernel
 static bool g_halo_enabled = true;           // pf_gemm_set_policy(-5) / (5): never / again the LDS-halo direct conv
+static bool g_halo_maps = true;              // pf_gemm_set_policy(-7) / (7): the upsamplers' shuffled output maps stay with the implicit GEMM / take the halo kernel
 static bool g_halo_wide = true;              // pf_gemm_set_policy(-6) / (6): only the N = 128 layers / also the 256- and 512-filter layers
 static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
@@ -310,9 +311,10 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 4 || force == -4) { pf_gemm8p_set_tail_split(force > 0); return 0; }
     if (force == 5 || force == -5) { g_halo_enabled = force > 0; return 0; }
     if (force == 6 || force == -6) { g_halo_wide = force > 0; return 0; }
+    if (force == 7 || force == -7) { g_halo_maps = force > 0; return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-6, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-7, 8, -8, 128, 192 or 256");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
@@ -435,7 +437,8 @@ static void conv_args(const pf_conv_desc* d, Args& a) {
 // 0 = gemm_kernel<true>
 static int conv_route(const pf_conv_desc* d, const Args& a) {
     if (g_narrow_enabled && pf_conv_narrow_supports(d)) return -1;
-    if (g_halo_enabled && gemm256_force() == 0 && pf_conv_halo_supports(d, g_halo_wide)) return -2;
+    if (g_halo_enabled && gemm256_force() == 0 && pf_conv_halo_supports(d, g_halo_wide) &&
+        (g_halo_maps || (d->st == 1 && d->sh == 1 && d->sw == 1))) return -2;
     if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) return 8;
     return pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force());
 }
