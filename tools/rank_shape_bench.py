@@ -4,7 +4,8 @@ The sequence-parallel DiT engine (pyflow_hip/flux_sp.py; replaces flux_block.py:
 trainer_misc/communicate.py:7-66) gives every rank a contiguous chunk of the merged rows and a share of the 30 heads.  A
 rank's kernels therefore have shapes that can be launched on a single device: this tool runs ONE rank's recorded launch
 list (rows L / P, uneven head map, both exchanges replaced by device copies of the same size: `PhantomComm`) at
-P = 1 / 2 / 4 / 8 for rank 0 (owns the text rows) and rank P - 1 (owns the current frame's rows) over a sample of the
+P = 2 / 4 / 8 for rank 0 (owns the text rows) and rank P - 1 (owns the current frame's rows) -- and the PRODUCTION single-GPU
+engine for the N = 1 row and, with batch 1, for the guidance-parallel rank of N = 2 -- over a sample of the
 93 (unit, stage) sequences of one video, interpolates over the units, weights with the schedule (20 / 10 steps), and adds
   * the exchange time from the bytes a rank sends per forward and the xGMI figures of the task statement
     (7 links x 153 GB/s per GPU, one link per peer pair; `--link-eff` of that is assumed achievable) -- reported both as
@@ -81,7 +82,7 @@ def main():
     ap.add_argument("--units", default="0,1,2,3,5,8,12,16,20,24,28,30")
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--decode-s", type=float, default=7.8, help="measured single-GPU tiled decode of the 241 frames (s)")
+    ap.add_argument("--decode-s", type=float, default=6.4, help="measured single-GPU tiled decode of the 241 frames (s)")
     ap.add_argument("--link-gbs", type=float, default=153.0)
     ap.add_argument("--link-eff", type=float, default=0.8)
     ap.add_argument("--latency-us", type=float, default=15.0, help="fixed cost of one grouped send/recv exchange")
@@ -97,6 +98,10 @@ def main():
         sd[k] = (torch.ones(shp, device=dev) if k.endswith(".weight") else torch.zeros(shp, device=dev)) if len(shp) == 1 \
             else torch.randn(shp, generator=g, device=dev) * 0.02
     eng = FluxEngineSP(sd, cfg, dev, comm=PhantomComm(0, 1))
+    # the PRODUCTION single-GPU engine (QK epilogue, side-stream text path, hipGraph replay): the N = 1 row every efficiency is
+    # quoted against, and -- with batch 1 -- the guidance-parallel rank of N = 2 (pyflow_hip/flux_cfg.py runs exactly this engine)
+    from pyflow_hip.flux import FluxEngine
+    eng1 = FluxEngine(sd, cfg, dev)
     del sd
     mask = torch.zeros(2, 128, dtype=torch.long)
     mask[0, :40] = 1
@@ -105,12 +110,47 @@ def main():
     pooled = torch.randn(2, 768)
     pooled1 = pooled[1:2].contiguous()
     eng.encode_context(enc)
+    eng1.encode_context(enc)
     units = sorted({int(x) for x in args.units.split(",")} | {0, 30})
     Ps = [int(x) for x in args.ranks.split(",")]
     d, B = 1920, 2
     link = args.link_gbs * 1e9 * args.link_eff
 
-    state = {"B": 2}
+    state = {"B": 2, "B1": 2}
+
+    def measure_single(u, s, nb=2):
+        """the production engine at (u, s): batch 2 = the single-GPU job, batch 1 = one guidance branch"""
+        if state["B1"] != nb:
+            eng1.encode_context(enc if nb == 2 else enc[1:2])
+            state["B1"] = nb
+        shapes = clips_for(u, s)
+        clips = [torch.randn(1, 16, *c, device=dev) for c in shapes]
+        plan = eng1.make_plan(shapes, mask if nb == 2 else mask[1:2])
+        ts_, pooled_ = ([500.0, 500.0], pooled) if nb == 2 else ([500.0], pooled1)
+        for _ in range(3):                                   # record, replay, graph replay
+            eng1.forward_tokens(plan, clips, ts_, pooled_, shared_clips=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.reps):
+            eng1.forward_tokens(plan, clips, ts_, pooled_, shared_clips=True)
+        e1.record()
+        host_ms = (time.perf_counter() - h0) / args.reps * 1e3
+        torch.cuda.synchronize()
+        dev_ms = e0.elapsed_time(e1) / args.reps
+        ops.PROFILER.records = {}
+        ops.PROFILER.enabled = True
+        eng1.forward_tokens(plan, clips, ts_, pooled_, shared_clips=True)
+        ops.PROFILER.enabled = False
+        torch.cuda.synchronize()
+        fam = {}
+        for name, sv in ops.PROFILER.summary().items():
+            key = name.split("<")[0].split("(")[0]
+            fam[key] = fam.get(key, 0.0) + sv["ms_total"]
+        ops.PROFILER.records = {}
+        del plan, clips
+        return dev_ms, host_ms, fam, 0, 30
 
     def measure(P, r, u, s, nb=2):
         """device ms, host ms of one forward of rank r of P at (u, s), and its kernel-family split.  nb = 1: ONE branch of the
@@ -170,15 +210,15 @@ def main():
     if 2 in Ps:          # guidance-parallel N = 2: a rank = the whole sequence, all heads, ONE branch of the CFG pair
         for s in range(3):
             for u in units:
-                dev_ms, host_ms, fam, nloc, mh = measure(1, 0, u, s, nb=1)
+                dev_ms, host_ms, fam, nloc, mh = measure_single(u, s, nb=1)
                 L = 128 + sum(c[0] * (c[1] // 2) * (c[2] // 2) for c in clips_for(u, s))
-                table[("g2", 0, u, s)] = dict(dev_ms=dev_ms, host_ms=host_ms, fam=fam, L=L, nloc=nloc, heads=mh)
-                print(f"guidance2 (batch 1) u={u:2d} s={s} L={L:5d}: {dev_ms:8.3f} ms device, {host_ms:6.3f} ms host", flush=True)
+                table[("g2", 0, u, s)] = dict(dev_ms=dev_ms, host_ms=host_ms, fam=fam, L=L, nloc=L, heads=mh)
+                print(f"guidance2 (production engine, batch 1) u={u:2d} s={s} L={L:5d}: {dev_ms:8.3f} ms device, {host_ms:6.3f} ms host", flush=True)
     for P in Ps:
         for r in sorted({0, P - 1}):
             for s in range(3):
                 for u in units:
-                    dev_ms, host_ms, fam, nloc, mh = measure(P, r, u, s)
+                    dev_ms, host_ms, fam, nloc, mh = measure_single(u, s) if P == 1 else measure(P, r, u, s)
                     L = 128 + sum(c[0] * (c[1] // 2) * (c[2] // 2) for c in clips_for(u, s))
                     table[(P, r, u, s)] = dict(dev_ms=dev_ms, host_ms=host_ms, fam=fam, L=L, nloc=nloc, heads=mh)
                     print(f"P={P} rank={r} u={u:2d} s={s} L={L:5d} rows={nloc:5d} heads={mh:2d}: {dev_ms:8.3f} ms device, "
