@@ -91,8 +91,10 @@ long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
  * 8 = force gemm8p whenever its epilogue flavour exists (bias + ONE of residual / fp32 output / GELU-tanh); -8 = never
  * gemm8p; -2 / 2 = never / again split K for skinny problems that bring a workspace; -3 / 3 = never / again
  * the narrow-N conv kernel (3x3x3 convs with <= 8 output channels: the decoder's conv_out); -4 / 4 = never / again
- * split the tail tiles of gemm8p problems that bring a workspace; 400 + c (c = 0..199) = measurement hook: the split's
- * assumed fixed cost in K-tile periods (default 4).  Default 0. */
+ * split the tail tiles of gemm8p problems that bring a workspace (also: the whole-launch K split of 32 .. 128-tile problems);
+ * -5 / 5 = never / again the LDS-halo direct conv; -6 / 6 = halo conv only for N = 128 / also for wider layers; -7 / 7 = the
+ * upsamplers' output maps stay with the implicit GEMM / take the halo kernel; 400 + c (c = 0..199) = measurement hook: the
+ * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0).  Default 0. */
 int pf_gemm_set_policy(int force);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =
  * gemm8p_kernel, BN > 0 = gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */
@@ -133,8 +135,9 @@ typedef struct {
 int pf_conv3d_bf16(const pf_conv_desc* d, pf_stream_t stream);
 int pf_conv3d_fuses_gn_stats(const pf_conv_desc* d);   /* 1 = pf_conv3d_bf16(d) accumulates d->gn_stats */
 /* which kernel pf_conv3d_bf16(d) launches: -1 conv_narrow_kernel (<= 8 filters: conv_out), -2 conv_halo128_kernel (LDS-halo
- * direct conv: 3 x 3 x 3 taps, 128 filters, 128 / 256 input channels, frames of whole 16 x 32 patches -- the decoder's
- * full-resolution resnets, modeling_resnet.py:115-150), 8 gemm8p_kernel, 128 / 192 / 256 gemm256_kernel<BN>, 0 the
+ * direct conv: 3 x 3 x 3 taps, N = 128 k filters, 128 / 256 / 512 input channels, frames of whole 16 x 32 patches, plain or
+ * pixel-shuffle / depth-to-time output map -- the decoder's resnet convs and upsamplers, modeling_resnet.py:115-150, 609-617,
+ * 716-729), 8 gemm8p_kernel, 128 / 192 / 256 gemm256_kernel<BN>, 0 the
  * 128 x 128 implicit GEMM; -100 = the descriptor is rejected */
 int pf_conv3d_which(const pf_conv_desc* d);
 
