@@ -22,6 +22,10 @@
 
 #include "../pyramid-flow_amd/csrc/attention.hip"
 
+namespace {
+#include "attn128_lab.h"
+}
+
 int pf_set_err(const char* m) {
     fprintf(stderr, "pf error: %s\n", m);
     return -1;
@@ -429,6 +433,7 @@ int main(int argc, char** argv) {
     a.Lp = Lp; a.L = L; a.H = H; a.B = B; a.Lt = pl.Lt; a.nqt = pl.nqt;
     a.a_lo = d_alo; a.a_hi = d_ahi; a.b_hi = d_bhi; a.tile_kv_end = d_te;
     a.sc = 0.125f * 1.4426950408889634f; a.hs_qk = 64; a.prio = 1; a.qt0 = 0;
+    a.V = (const bf16_t*)(dqkv + d); a.ldv = ld; a.sV = (long long)L * ld; a.hs_v = 64;       // token-major V (VROW kernels)
     const int grid = pl.nqt * H * B;
 
     struct Var { const char* name; std::function<void()> run; bool check; };
@@ -457,6 +462,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)attn64_kernel<2, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
+    CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 33, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM64));
     CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
     CK(hipFuncSetAttribute((const void*)(attn64_kernel<2, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, SM128));
     const int grid128 = ((pl.nqt + 3) / 4) * H * B;
@@ -488,6 +494,12 @@ int main(int argc, char** argv) {
     vars.push_back({"attn64 FAST, MFMA row sums + FIXUP launch", [&] {
         hipLaunchKernelGGL((attn64_kernel<2, 33>), dim3(grid64), dim3(256), SM64, st, a);
         hipLaunchKernelGGL((attn64_kernel<2, 4>), dim3(grid64), dim3(256), SM64, st, a); }, true});
+    // round 4: one wave per SIMD, four 32-row blocks per wave (512 rows per workgroup), Q in registers, V token-major
+    const int grid512 = ((pl.nqt + 3) / 4) * H * B;
+    vars.push_back({"attn64 FAST | MMSUM | VROW alone (shipped fast pass)", [&] {
+        hipLaunchKernelGGL((attn64_kernel<2, 33, 4, true>), dim3(grid64), dim3(256), SM64, st, a); }, true});
+    vars.push_back({"attn128 FAST (1 wave / SIMD, 4 blocks / wave) alone", [&] {
+        hipLaunchKernelGGL((attn128_fast_kernel<true>), dim3(grid512), dim3(256), 2 * ABUF, st, a); }, true});
     vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), SM64, st, a); }, false});
     ABLV("stamped (occ 3)", lab::A_STAMP, 3, true);
