@@ -257,3 +257,5 @@ __global__ __launch_bounds__(256, 1) void attn128_fast_kernel(const AArgs p) {
             }
     }
 }
+
+

@@ -24,6 +24,7 @@
 
 namespace {
 #include "attn128_lab.h"
+#include "attn128_pipe.h"
 }
 
 int pf_set_err(const char* m) {
@@ -500,6 +501,10 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((attn64_kernel<2, 33, 4, true>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn128 FAST (1 wave / SIMD, 4 blocks / wave) alone", [&] {
         hipLaunchKernelGGL((attn128_fast_kernel<true>), dim3(grid512), dim3(256), 2 * ABUF, st, a); }, true});
+    vars.push_back({"attn128 pipe (hand-placed, 1 wave / SIMD) alone", [&] {
+        hipLaunchKernelGGL((attn128_pipe_kernel<0, 0>), dim3(grid512), dim3(256), 3 * ABUF, st, a); }, true});
+    vars.push_back({"attn128 pipe, fillers in pairs, alone", [&] {
+        hipLaunchKernelGGL((attn128_pipe_kernel<0, 5>), dim3(grid512), dim3(256), 3 * ABUF, st, a); }, true});
     vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), SM64, st, a); }, false});
     ABLV("stamped (occ 3)", lab::A_STAMP, 3, true);
@@ -605,6 +610,28 @@ int main(int argc, char** argv) {
         printf("attn64 stamped%s: cycles per processed 64-key tile and wave (2 x 32 rows; the matrix pipe needs 1024):\n", v64 == 3 ? " FAST" : "");
         for (int i = 0; i < 7; ++i) printf("   %-44s %8.1f  (%4.1f%%)\n", nm[i], sum[i] / sum[7], 100 * sum[i] / tot);
         printf("   %-44s %8.1f\n", "total", tot / sum[7]);
+    }
+    for (int sv = 0; sv < 7; ++sv) {
+        CK(hipMemset(d_dbg, 0, nwg_max * 4 * lab::NPH * 4));
+        const char* nm[7] = {"loop-stamped", "step-stamped", "step-stamped, NO V fragment reads", "step-stamped, NO barrier", "step-stamped, NO further DMA", "step-stamped, NO K fragment reads", "step-stamped, fillers in pairs"};
+        switch (sv) {
+            case 0: hipLaunchKernelGGL((attn128_pipe_kernel<1, 0>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+            case 1: hipLaunchKernelGGL((attn128_pipe_kernel<2, 0>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+            case 2: hipLaunchKernelGGL((attn128_pipe_kernel<2, 1>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+            case 3: hipLaunchKernelGGL((attn128_pipe_kernel<2, 2>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+            case 4: hipLaunchKernelGGL((attn128_pipe_kernel<2, 3>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+            case 5: hipLaunchKernelGGL((attn128_pipe_kernel<2, 4>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+            default: hipLaunchKernelGGL((attn128_pipe_kernel<2, 5>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
+        }
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned> hd((size_t)grid512 * 4 * 8);
+        CK(hipMemcpy(hd.data(), d_dbg, hd.size() * 4, hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        for (size_t w = 0; w < (size_t)grid512 * 4; ++w)
+            for (int i = 0; i < 8; ++i) sum[i] += hd[w * 8 + i];
+        printf("attn128 pipe %-36s cycles per 64-key tile and wave (4 x 32 rows; the matrix pipe needs 2304): loop %.1f", nm[sv], sum[6] / sum[7]);
+        if (sv >= 1) printf("   steps A %.1f  B %.1f  C %.1f  D %.1f", sum[0] / sum[7], sum[1] / sum[7], sum[2] / sum[7], sum[3] / sum[7]);
+        printf("\n");
     }
     CK(hipMemset(d_dbg, 0, nwg_max * 4 * lab::NPH * 4));
     hipLaunchKernelGGL((lab::attn_abl_kernel<lab::A_STAMP, 3>), dim3(grid), dim3(256), 0, st, a, d_dbg);
