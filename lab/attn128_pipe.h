@@ -37,8 +37,12 @@ DEV_PIPE void pq_qk(f32x16_t& s, const bf16x8_t& q) {                 // S^T hal
 template <int X, int I, int G>
 DEV_PIPE void pq_pv(const u32x4_t& pfrag) {                            // O^T block X half I += V^T(slot G) P^T(slot G)
     constexpr int O0 = 32 * X + 16 * I, V0 = 176 + 16 * I + 4 * G;
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%0:%1], a[%2:%3], %4, a[%0:%1]" ::"n"(O0), "n"(O0 + 15), "n"(V0), "n"(V0 + 3), "v"(pfrag));
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], a[%2:%3], %4, a[%0:%1]" ::"n"(O0), "n"(O0 + 15), "n"(V0), "n"(V0 + 3), "v"(pfrag));
 }
+// the same statements with their quarter (v_cvt_pk of the previous quarter, two v_exp_f32) in ONE asm block: between the
+// statements of a block the compiler adds nothing (between separate asm statements it put an s_nop behind most MFMAs, and a
+// sixth issue slot per MFMA gap costs ~4 cycles: MI355X_MICROARCH.md "one wave per SIMD")
+#define PQ_QUARTER "\n\tv_cvt_pk_bf16_f32 %[w], %[ca], %[cb]\n\tv_exp_f32 %[ea], %[xa]\n\tv_exp_f32 %[eb], %[xb]"
 template <int X>
 DEV_PIPE void pq_ls(const bf16x8_t& ones, const u32x4_t& pfrag) {      // row sums of block X += (0 / 1 operand) P^T(slot)
     constexpr int L0 = 128 + 4 * X;
@@ -73,7 +77,7 @@ DEV_PIPE void pq_read_v(unsigned a0, unsigned a1) {                    // V frag
                    "v"(a0), "v"(a1), "n"(2048 * G), "n"(2048 * G + 1024) : "memory");
 }
 
-// VAR (timing experiments only, results wrong): 1 no V fragment reads, 2 no barrier, 3 no DMA of further tiles, 4 no K fragment reads, 5 fillers in pairs (M M f f)
+// VAR (timing experiments only, results wrong): 1 no V fragment reads, 2 no barrier, 3 no DMA of further tiles, 4 no K fragment reads, 5 MFMA and quarter as separate asm statements
 template <int STAMP, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void attn128_pipe_kernel(const AArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,6 +207,21 @@ __global__ __launch_bounds__(256, 1) void attn128_pipe_kernel(const AArgs p) {
 #define QKM(X, KS, I, S) pq_qk<KS, I>(S[I], qf[X][KS]);
 #define PVM(X, I, G, PF) pq_pv<X, I, G>(PF[G]);
 #define LSM(X, G, PF) pq_ls<X>(ones_a, PF[G]);
+#define PQ_Q_OUT(W, EA, EB) [w] "=&v"(W), [ea] "=&v"(EA), [eb] "=&v"(EB)
+#define PQ_Q_IN(CA, CB, XA, XB) [ca] "v"(CA), [cb] "v"(CB), [xa] "v"(XA), [xb] "v"(XB)
+#define QKF0(X, KS, I, S, W, CA, CB, EA, XA, EB, XB)                                                                     \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %[s], a[%[k0]:%[k1]], %[q], 0" PQ_QUARTER                                    \
+                 : [s] "=&v"(S[I]), PQ_Q_OUT(W, EA, EB)                                                                   \
+                 : [k0] "n"(144 + 16 * (I) + 4 * (KS)), [k1] "n"(147 + 16 * (I) + 4 * (KS)), [q] "v"(qf[X][KS]), PQ_Q_IN(CA, CB, XA, XB));
+#define QKF(X, KS, I, S, W, CA, CB, EA, XA, EB, XB)                                                                      \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %[s], a[%[k0]:%[k1]], %[q], %[s]" PQ_QUARTER                                 \
+                 : [s] "+v"(S[I]), PQ_Q_OUT(W, EA, EB)                                                                    \
+                 : [k0] "n"(144 + 16 * (I) + 4 * (KS)), [k1] "n"(147 + 16 * (I) + 4 * (KS)), [q] "v"(qf[X][KS]), PQ_Q_IN(CA, CB, XA, XB));
+#define PVF(X, I, G, PF, W, CA, CB, EA, XA, EB, XB)                                                                      \
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%[o0]:%[o1]], a[%[v0]:%[v1]], %[p], a[%[o0]:%[o1]]" PQ_QUARTER             \
+                 : PQ_Q_OUT(W, EA, EB)                                                                                    \
+                 : [o0] "n"(32 * (X) + 16 * (I)), [o1] "n"(32 * (X) + 16 * (I) + 15), [v0] "n"(176 + 16 * (I) + 4 * (G)),  \
+                   [v1] "n"(179 + 16 * (I) + 4 * (G)), [p] "v"(PF[G]), PQ_Q_IN(CA, CB, XA, XB));
 #define RDK(KS) if (VAR != 4) pq_read_k<KS>(foff[KS] + kbuf_next);
 #define RDV(G) if (VAR != 1) pq_read_v<G>(voff0 + vbuf, voff1 + vbuf);
 #define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -253,239 +272,175 @@ __global__ __launch_bounds__(256, 1) void attn128_pipe_kernel(const AArgs p) {
         const int j0 = jt * KB;
         const bool masked = (j0 < p.Lt) || (j0 + KB > wmin_s);
         if constexpr (VAR == 5) {
-        // GENERATED PAIR BODY BEGIN (lab/gen_attn128_body.py, pair mode)
+        // GENERATED PAIR BODY BEGIN (lab/gen_attn128_body.py, separate statements)
         // ---- step A: QK(jt, 1) -> sb, PV(jt - 1, 3) from pb, exp(sa) -> pa; the V fragments of tile jt slot by slot behind
         //      the PV MFMAs that read the old ones
         QKM(1, 0, 0, sb)
         MASKB(0, sa)
-        CVT(pb[3][3], e1a, e1b)          /* the last quarter of the previous tile's block 3 */
-        EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
+        CVT(pb[3][3], e1a, e1b) EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
         PVM(3, 0, 0, pb)
+        CVT(pa[0][0], e0a, e0b) EXP(e1a, sa[0][2]) EXP(e1b, sa[0][3])
         QKM(1, 0, 1, sb)
-        CVT(pa[0][0], e0a, e0b)
-        EXP(e1a, sa[0][2]) EXP(e1b, sa[0][3])
-        CVT(pa[0][1], e1a, e1b)
-        EXP(e0a, sa[0][4]) EXP(e0b, sa[0][5])
+        CVT(pa[0][1], e1a, e1b) EXP(e0a, sa[0][4]) EXP(e0b, sa[0][5])
         PVM(3, 1, 0, pb)
+        CVT(pa[0][2], e0a, e0b) EXP(e1a, sa[0][6]) EXP(e1b, sa[0][7])
         LSM(3, 0, pb)
         QKM(1, 1, 0, sb)
-        CVT(pa[0][2], e0a, e0b)
-        EXP(e1a, sa[0][6]) EXP(e1b, sa[0][7])
-        CVT(pa[0][3], e1a, e1b)
-        EXP(e0a, sa[0][8]) EXP(e0b, sa[0][9])
+        CVT(pa[0][3], e1a, e1b) EXP(e0a, sa[0][8]) EXP(e0b, sa[0][9])
         RDV(0)
         PVM(3, 0, 1, pb)
+        CVT(pa[1][0], e0a, e0b) EXP(e1a, sa[0][10]) EXP(e1b, sa[0][11])
         QKM(1, 1, 1, sb)
-        CVT(pa[1][0], e0a, e0b)
-        EXP(e1a, sa[0][10]) EXP(e1b, sa[0][11])
-        CVT(pa[1][1], e1a, e1b)
-        EXP(e0a, sa[0][12]) EXP(e0b, sa[0][13])
+        CVT(pa[1][1], e1a, e1b) EXP(e0a, sa[0][12]) EXP(e0b, sa[0][13])
         PVM(3, 1, 1, pb)
+        CVT(pa[1][2], e0a, e0b) EXP(e1a, sa[0][14]) EXP(e1b, sa[0][15])
         LSM(3, 1, pb)
         QKM(1, 2, 0, sb)
-        CVT(pa[1][2], e0a, e0b)
-        EXP(e1a, sa[0][14]) EXP(e1b, sa[0][15])
-        CVT(pa[1][3], e1a, e1b)
-        EXP(e0a, sa[1][0]) EXP(e0b, sa[1][1])
+        CVT(pa[1][3], e1a, e1b) EXP(e0a, sa[1][0]) EXP(e0b, sa[1][1])
         RDV(1)
         PVM(3, 0, 2, pb)
+        CVT(pa[2][0], e0a, e0b) EXP(e1a, sa[1][2]) EXP(e1b, sa[1][3])
         QKM(1, 2, 1, sb)
-        CVT(pa[2][0], e0a, e0b)
-        EXP(e1a, sa[1][2]) EXP(e1b, sa[1][3])
-        CVT(pa[2][1], e1a, e1b)
-        EXP(e0a, sa[1][4]) EXP(e0b, sa[1][5])
+        CVT(pa[2][1], e1a, e1b) EXP(e0a, sa[1][4]) EXP(e0b, sa[1][5])
         PVM(3, 1, 2, pb)
+        CVT(pa[2][2], e0a, e0b) EXP(e1a, sa[1][6]) EXP(e1b, sa[1][7])
         LSM(3, 2, pb)
         QKM(1, 3, 0, sb)
-        CVT(pa[2][2], e0a, e0b)
-        EXP(e1a, sa[1][6]) EXP(e1b, sa[1][7])
-        CVT(pa[2][3], e1a, e1b)
-        EXP(e0a, sa[1][8]) EXP(e0b, sa[1][9])
+        CVT(pa[2][3], e1a, e1b) EXP(e0a, sa[1][8]) EXP(e0b, sa[1][9])
         RDV(2)
         PVM(3, 0, 3, pb)
+        CVT(pa[3][0], e0a, e0b) EXP(e1a, sa[1][10]) EXP(e1b, sa[1][11])
         QKM(1, 3, 1, sb)
-        CVT(pa[3][0], e0a, e0b)
-        EXP(e1a, sa[1][10]) EXP(e1b, sa[1][11])
-        CVT(pa[3][1], e1a, e1b)
-        EXP(e0a, sa[1][12]) EXP(e0b, sa[1][13])
+        CVT(pa[3][1], e1a, e1b) EXP(e0a, sa[1][12]) EXP(e0b, sa[1][13])
         PVM(3, 1, 3, pb)
+        CVT(pa[3][2], e0a, e0b) EXP(e1a, sa[1][14]) EXP(e1b, sa[1][15])
         LSM(3, 3, pb)
-        CVT(pa[3][2], e0a, e0b)
-        EXP(e1a, sa[1][14]) EXP(e1b, sa[1][15])
         stamp(0);
         // ---- step B: QK(jt, 2) -> sa, exp(sb) -> pb; the tile boundary; PV(jt, 0) from pa
         QKM(2, 0, 0, sa)
         MASKB(1, sb)
-        CVT(pa[3][3], e1a, e1b)
-        EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
+        CVT(pa[3][3], e1a, e1b) EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
         RDV(3)
         QKM(2, 0, 1, sa)
+        CVT(pb[0][0], e0a, e0b) EXP(e1a, sb[0][2]) EXP(e1b, sb[0][3])
         QKM(2, 1, 0, sa)
-        CVT(pb[0][0], e0a, e0b)
-        EXP(e1a, sb[0][2]) EXP(e1b, sb[0][3])
-        CVT(pb[0][1], e1a, e1b)
-        EXP(e0a, sb[0][4]) EXP(e0b, sb[0][5])
+        CVT(pb[0][1], e1a, e1b) EXP(e0a, sb[0][4]) EXP(e0b, sb[0][5])
         QKM(2, 1, 1, sa)
-        CVT(pb[0][2], e0a, e0b)
-        EXP(e1a, sb[0][6]) EXP(e1b, sb[0][7])
+        CVT(pb[0][2], e0a, e0b) EXP(e1a, sb[0][6]) EXP(e1b, sb[0][7])
         BOUNDARY()
         LGKM0()
         PVM(0, 0, 0, pa)
+        CVT(pb[0][3], e1a, e1b) EXP(e0a, sb[0][8]) EXP(e0b, sb[0][9])
         PVM(0, 1, 0, pa)
-        CVT(pb[0][3], e1a, e1b)
-        EXP(e0a, sb[0][8]) EXP(e0b, sb[0][9])
-        CVT(pb[1][0], e0a, e0b)
-        EXP(e1a, sb[0][10]) EXP(e1b, sb[0][11])
+        CVT(pb[1][0], e0a, e0b) EXP(e1a, sb[0][10]) EXP(e1b, sb[0][11])
         LSM(0, 0, pa)
         QKM(2, 2, 0, sa)
+        CVT(pb[1][1], e1a, e1b) EXP(e0a, sb[0][12]) EXP(e0b, sb[0][13])
         PVM(0, 0, 1, pa)
-        CVT(pb[1][1], e1a, e1b)
-        EXP(e0a, sb[0][12]) EXP(e0b, sb[0][13])
-        CVT(pb[1][2], e0a, e0b)
-        EXP(e1a, sb[0][14]) EXP(e1b, sb[0][15])
+        CVT(pb[1][2], e0a, e0b) EXP(e1a, sb[0][14]) EXP(e1b, sb[0][15])
         QKM(2, 2, 1, sa)
+        CVT(pb[1][3], e1a, e1b) EXP(e0a, sb[1][0]) EXP(e0b, sb[1][1])
         PVM(0, 1, 1, pa)
-        CVT(pb[1][3], e1a, e1b)
-        EXP(e0a, sb[1][0]) EXP(e0b, sb[1][1])
-        CVT(pb[2][0], e0a, e0b)
-        EXP(e1a, sb[1][2]) EXP(e1b, sb[1][3])
+        CVT(pb[2][0], e0a, e0b) EXP(e1a, sb[1][2]) EXP(e1b, sb[1][3])
         LSM(0, 1, pa)
         QKM(2, 3, 0, sa)
+        CVT(pb[2][1], e1a, e1b) EXP(e0a, sb[1][4]) EXP(e0b, sb[1][5])
         PVM(0, 0, 2, pa)
-        CVT(pb[2][1], e1a, e1b)
-        EXP(e0a, sb[1][4]) EXP(e0b, sb[1][5])
-        CVT(pb[2][2], e0a, e0b)
-        EXP(e1a, sb[1][6]) EXP(e1b, sb[1][7])
+        CVT(pb[2][2], e0a, e0b) EXP(e1a, sb[1][6]) EXP(e1b, sb[1][7])
         QKM(2, 3, 1, sa)
+        CVT(pb[2][3], e1a, e1b) EXP(e0a, sb[1][8]) EXP(e0b, sb[1][9])
         PVM(0, 1, 2, pa)
-        CVT(pb[2][3], e1a, e1b)
-        EXP(e0a, sb[1][8]) EXP(e0b, sb[1][9])
-        CVT(pb[3][0], e0a, e0b)
-        EXP(e1a, sb[1][10]) EXP(e1b, sb[1][11])
+        CVT(pb[3][0], e0a, e0b) EXP(e1a, sb[1][10]) EXP(e1b, sb[1][11])
         LSM(0, 2, pa)
         PVM(0, 0, 3, pa)
+        CVT(pb[3][1], e1a, e1b) EXP(e0a, sb[1][12]) EXP(e0b, sb[1][13])
         PVM(0, 1, 3, pa)
-        CVT(pb[3][1], e1a, e1b)
-        EXP(e0a, sb[1][12]) EXP(e0b, sb[1][13])
-        CVT(pb[3][2], e0a, e0b)
-        EXP(e1a, sb[1][14]) EXP(e1b, sb[1][15])
+        CVT(pb[3][2], e0a, e0b) EXP(e1a, sb[1][14]) EXP(e1b, sb[1][15])
         LSM(0, 3, pa)
         stamp(1);
         // ---- step C: QK(jt, 3) -> sb, PV(jt, 1) from pb, exp(sa) -> pa; the K fragments of tile jt + 1 k-slice by k-slice
         //      behind the QK MFMAs that read the old ones
         QKM(3, 0, 0, sb)
         MASKB(2, sa)
-        CVT(pb[3][3], e1a, e1b)
-        EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
+        CVT(pb[3][3], e1a, e1b) EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
         PVM(1, 0, 0, pb)
+        CVT(pa[0][0], e0a, e0b) EXP(e1a, sa[0][2]) EXP(e1b, sa[0][3])
         QKM(3, 0, 1, sb)
-        CVT(pa[0][0], e0a, e0b)
-        EXP(e1a, sa[0][2]) EXP(e1b, sa[0][3])
-        CVT(pa[0][1], e1a, e1b)
-        EXP(e0a, sa[0][4]) EXP(e0b, sa[0][5])
+        CVT(pa[0][1], e1a, e1b) EXP(e0a, sa[0][4]) EXP(e0b, sa[0][5])
         PVM(1, 1, 0, pb)
-        CVT(pa[0][2], e0a, e0b)
-        EXP(e1a, sa[0][6]) EXP(e1b, sa[0][7])
+        CVT(pa[0][2], e0a, e0b) EXP(e1a, sa[0][6]) EXP(e1b, sa[0][7])
         RDK(0)
         LSM(1, 0, pb)
         QKM(3, 1, 0, sb)
+        CVT(pa[0][3], e1a, e1b) EXP(e0a, sa[0][8]) EXP(e0b, sa[0][9])
         PVM(1, 0, 1, pb)
-        CVT(pa[0][3], e1a, e1b)
-        EXP(e0a, sa[0][8]) EXP(e0b, sa[0][9])
-        CVT(pa[1][0], e0a, e0b)
-        EXP(e1a, sa[0][10]) EXP(e1b, sa[0][11])
+        CVT(pa[1][0], e0a, e0b) EXP(e1a, sa[0][10]) EXP(e1b, sa[0][11])
         QKM(3, 1, 1, sb)
+        CVT(pa[1][1], e1a, e1b) EXP(e0a, sa[0][12]) EXP(e0b, sa[0][13])
         PVM(1, 1, 1, pb)
-        CVT(pa[1][1], e1a, e1b)
-        EXP(e0a, sa[0][12]) EXP(e0b, sa[0][13])
-        CVT(pa[1][2], e0a, e0b)
-        EXP(e1a, sa[0][14]) EXP(e1b, sa[0][15])
+        CVT(pa[1][2], e0a, e0b) EXP(e1a, sa[0][14]) EXP(e1b, sa[0][15])
         RDK(1)
         LSM(1, 1, pb)
         QKM(3, 2, 0, sb)
+        CVT(pa[1][3], e1a, e1b) EXP(e0a, sa[1][0]) EXP(e0b, sa[1][1])
         PVM(1, 0, 2, pb)
-        CVT(pa[1][3], e1a, e1b)
-        EXP(e0a, sa[1][0]) EXP(e0b, sa[1][1])
-        CVT(pa[2][0], e0a, e0b)
-        EXP(e1a, sa[1][2]) EXP(e1b, sa[1][3])
+        CVT(pa[2][0], e0a, e0b) EXP(e1a, sa[1][2]) EXP(e1b, sa[1][3])
         QKM(3, 2, 1, sb)
+        CVT(pa[2][1], e1a, e1b) EXP(e0a, sa[1][4]) EXP(e0b, sa[1][5])
         PVM(1, 1, 2, pb)
-        CVT(pa[2][1], e1a, e1b)
-        EXP(e0a, sa[1][4]) EXP(e0b, sa[1][5])
-        CVT(pa[2][2], e0a, e0b)
-        EXP(e1a, sa[1][6]) EXP(e1b, sa[1][7])
+        CVT(pa[2][2], e0a, e0b) EXP(e1a, sa[1][6]) EXP(e1b, sa[1][7])
         RDK(2)
         LSM(1, 2, pb)
         QKM(3, 3, 0, sb)
+        CVT(pa[2][3], e1a, e1b) EXP(e0a, sa[1][8]) EXP(e0b, sa[1][9])
         PVM(1, 0, 3, pb)
-        CVT(pa[2][3], e1a, e1b)
-        EXP(e0a, sa[1][8]) EXP(e0b, sa[1][9])
-        CVT(pa[3][0], e0a, e0b)
-        EXP(e1a, sa[1][10]) EXP(e1b, sa[1][11])
+        CVT(pa[3][0], e0a, e0b) EXP(e1a, sa[1][10]) EXP(e1b, sa[1][11])
         QKM(3, 3, 1, sb)
+        CVT(pa[3][1], e1a, e1b) EXP(e0a, sa[1][12]) EXP(e0b, sa[1][13])
         PVM(1, 1, 3, pb)
-        CVT(pa[3][1], e1a, e1b)
-        EXP(e0a, sa[1][12]) EXP(e0b, sa[1][13])
-        CVT(pa[3][2], e0a, e0b)
-        EXP(e1a, sa[1][14]) EXP(e1b, sa[1][15])
+        CVT(pa[3][2], e0a, e0b) EXP(e1a, sa[1][14]) EXP(e1b, sa[1][15])
         LSM(1, 3, pb)
         RDK(3)
         stamp(2);
         // ---- step D: PV(jt, 2) from pa, QK(jt + 1, 0) -> sa (on the last tile: of stale K fragments, never read), exp(sb) -> pb
         PVM(2, 0, 0, pa)
         MASKB(3, sb)
-        CVT(pa[3][3], e1a, e1b)
-        EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
+        CVT(pa[3][3], e1a, e1b) EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
         PVM(2, 1, 0, pa)
+        CVT(pb[0][0], e0a, e0b) EXP(e1a, sb[0][2]) EXP(e1b, sb[0][3])
         LSM(2, 0, pa)
-        CVT(pb[0][0], e0a, e0b)
-        EXP(e1a, sb[0][2]) EXP(e1b, sb[0][3])
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         QKM(0, 0, 0, sa)
+        CVT(pb[0][1], e1a, e1b) EXP(e0a, sb[0][4]) EXP(e0b, sb[0][5])
         QKM(0, 0, 1, sa)
-        CVT(pb[0][1], e1a, e1b)
-        EXP(e0a, sb[0][4]) EXP(e0b, sb[0][5])
-        CVT(pb[0][2], e0a, e0b)
-        EXP(e1a, sb[0][6]) EXP(e1b, sb[0][7])
+        CVT(pb[0][2], e0a, e0b) EXP(e1a, sb[0][6]) EXP(e1b, sb[0][7])
         QKM(0, 1, 0, sa)
+        CVT(pb[0][3], e1a, e1b) EXP(e0a, sb[0][8]) EXP(e0b, sb[0][9])
         PVM(2, 0, 1, pa)
-        CVT(pb[0][3], e1a, e1b)
-        EXP(e0a, sb[0][8]) EXP(e0b, sb[0][9])
-        CVT(pb[1][0], e0a, e0b)
-        EXP(e1a, sb[0][10]) EXP(e1b, sb[0][11])
+        CVT(pb[1][0], e0a, e0b) EXP(e1a, sb[0][10]) EXP(e1b, sb[0][11])
         QKM(0, 1, 1, sa)
+        CVT(pb[1][1], e1a, e1b) EXP(e0a, sb[0][12]) EXP(e0b, sb[0][13])
         PVM(2, 1, 1, pa)
-        CVT(pb[1][1], e1a, e1b)
-        EXP(e0a, sb[0][12]) EXP(e0b, sb[0][13])
-        CVT(pb[1][2], e0a, e0b)
-        EXP(e1a, sb[0][14]) EXP(e1b, sb[0][15])
+        CVT(pb[1][2], e0a, e0b) EXP(e1a, sb[0][14]) EXP(e1b, sb[0][15])
         LSM(2, 1, pa)
         QKM(0, 2, 0, sa)
+        CVT(pb[1][3], e1a, e1b) EXP(e0a, sb[1][0]) EXP(e0b, sb[1][1])
         PVM(2, 0, 2, pa)
-        CVT(pb[1][3], e1a, e1b)
-        EXP(e0a, sb[1][0]) EXP(e0b, sb[1][1])
-        CVT(pb[2][0], e0a, e0b)
-        EXP(e1a, sb[1][2]) EXP(e1b, sb[1][3])
+        CVT(pb[2][0], e0a, e0b) EXP(e1a, sb[1][2]) EXP(e1b, sb[1][3])
         QKM(0, 2, 1, sa)
+        CVT(pb[2][1], e1a, e1b) EXP(e0a, sb[1][4]) EXP(e0b, sb[1][5])
         PVM(2, 1, 2, pa)
-        CVT(pb[2][1], e1a, e1b)
-        EXP(e0a, sb[1][4]) EXP(e0b, sb[1][5])
-        CVT(pb[2][2], e0a, e0b)
-        EXP(e1a, sb[1][6]) EXP(e1b, sb[1][7])
+        CVT(pb[2][2], e0a, e0b) EXP(e1a, sb[1][6]) EXP(e1b, sb[1][7])
         LSM(2, 2, pa)
         LGKM0()
         QKM(0, 3, 0, sa)
+        CVT(pb[2][3], e1a, e1b) EXP(e0a, sb[1][8]) EXP(e0b, sb[1][9])
         PVM(2, 0, 3, pa)
-        CVT(pb[2][3], e1a, e1b)
-        EXP(e0a, sb[1][8]) EXP(e0b, sb[1][9])
-        CVT(pb[3][0], e0a, e0b)
-        EXP(e1a, sb[1][10]) EXP(e1b, sb[1][11])
+        CVT(pb[3][0], e0a, e0b) EXP(e1a, sb[1][10]) EXP(e1b, sb[1][11])
         QKM(0, 3, 1, sa)
+        CVT(pb[3][1], e1a, e1b) EXP(e0a, sb[1][12]) EXP(e0b, sb[1][13])
         PVM(2, 1, 3, pa)
-        CVT(pb[3][1], e1a, e1b)
-        EXP(e0a, sb[1][12]) EXP(e0b, sb[1][13])
-        CVT(pb[3][2], e0a, e0b)
-        EXP(e1a, sb[1][14]) EXP(e1b, sb[1][15])
+        CVT(pb[3][2], e0a, e0b) EXP(e1a, sb[1][14]) EXP(e1b, sb[1][15])
         LSM(2, 3, pa)
         stamp(3);
         // GENERATED PAIR BODY END
@@ -495,234 +450,110 @@ __global__ __launch_bounds__(256, 1) void attn128_pipe_kernel(const AArgs p) {
         //      the PV MFMAs that read the old ones
         QKM(1, 0, 0, sb)
         MASKB(0, sa)
-        CVT(pb[3][3], e1a, e1b)          /* the last quarter of the previous tile's block 3 */
-        EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
-        PVM(3, 0, 0, pb)
-        CVT(pa[0][0], e0a, e0b)
-        EXP(e1a, sa[0][2]) EXP(e1b, sa[0][3])
-        QKM(1, 0, 1, sb)
-        CVT(pa[0][1], e1a, e1b)
-        EXP(e0a, sa[0][4]) EXP(e0b, sa[0][5])
-        PVM(3, 1, 0, pb)
-        CVT(pa[0][2], e0a, e0b)
-        EXP(e1a, sa[0][6]) EXP(e1b, sa[0][7])
+        CVT(pb[3][3], e1a, e1b) EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
+        PVF(3, 0, 0, pb, pa[0][0], e0a, e0b, e1a, sa[0][2], e1b, sa[0][3])
+        QKF0(1, 0, 1, sb, pa[0][1], e1a, e1b, e0a, sa[0][4], e0b, sa[0][5])
+        PVF(3, 1, 0, pb, pa[0][2], e0a, e0b, e1a, sa[0][6], e1b, sa[0][7])
         LSM(3, 0, pb)
-        QKM(1, 1, 0, sb)
-        CVT(pa[0][3], e1a, e1b)
-        EXP(e0a, sa[0][8]) EXP(e0b, sa[0][9])
+        QKF(1, 1, 0, sb, pa[0][3], e1a, e1b, e0a, sa[0][8], e0b, sa[0][9])
         RDV(0)
-        PVM(3, 0, 1, pb)
-        CVT(pa[1][0], e0a, e0b)
-        EXP(e1a, sa[0][10]) EXP(e1b, sa[0][11])
-        QKM(1, 1, 1, sb)
-        CVT(pa[1][1], e1a, e1b)
-        EXP(e0a, sa[0][12]) EXP(e0b, sa[0][13])
-        PVM(3, 1, 1, pb)
-        CVT(pa[1][2], e0a, e0b)
-        EXP(e1a, sa[0][14]) EXP(e1b, sa[0][15])
+        PVF(3, 0, 1, pb, pa[1][0], e0a, e0b, e1a, sa[0][10], e1b, sa[0][11])
+        QKF(1, 1, 1, sb, pa[1][1], e1a, e1b, e0a, sa[0][12], e0b, sa[0][13])
+        PVF(3, 1, 1, pb, pa[1][2], e0a, e0b, e1a, sa[0][14], e1b, sa[0][15])
         LSM(3, 1, pb)
-        QKM(1, 2, 0, sb)
-        CVT(pa[1][3], e1a, e1b)
-        EXP(e0a, sa[1][0]) EXP(e0b, sa[1][1])
+        QKF(1, 2, 0, sb, pa[1][3], e1a, e1b, e0a, sa[1][0], e0b, sa[1][1])
         RDV(1)
-        PVM(3, 0, 2, pb)
-        CVT(pa[2][0], e0a, e0b)
-        EXP(e1a, sa[1][2]) EXP(e1b, sa[1][3])
-        QKM(1, 2, 1, sb)
-        CVT(pa[2][1], e1a, e1b)
-        EXP(e0a, sa[1][4]) EXP(e0b, sa[1][5])
-        PVM(3, 1, 2, pb)
-        CVT(pa[2][2], e0a, e0b)
-        EXP(e1a, sa[1][6]) EXP(e1b, sa[1][7])
+        PVF(3, 0, 2, pb, pa[2][0], e0a, e0b, e1a, sa[1][2], e1b, sa[1][3])
+        QKF(1, 2, 1, sb, pa[2][1], e1a, e1b, e0a, sa[1][4], e0b, sa[1][5])
+        PVF(3, 1, 2, pb, pa[2][2], e0a, e0b, e1a, sa[1][6], e1b, sa[1][7])
         LSM(3, 2, pb)
-        QKM(1, 3, 0, sb)
-        CVT(pa[2][3], e1a, e1b)
-        EXP(e0a, sa[1][8]) EXP(e0b, sa[1][9])
+        QKF(1, 3, 0, sb, pa[2][3], e1a, e1b, e0a, sa[1][8], e0b, sa[1][9])
         RDV(2)
-        PVM(3, 0, 3, pb)
-        CVT(pa[3][0], e0a, e0b)
-        EXP(e1a, sa[1][10]) EXP(e1b, sa[1][11])
-        QKM(1, 3, 1, sb)
-        CVT(pa[3][1], e1a, e1b)
-        EXP(e0a, sa[1][12]) EXP(e0b, sa[1][13])
-        PVM(3, 1, 3, pb)
-        CVT(pa[3][2], e0a, e0b)
-        EXP(e1a, sa[1][14]) EXP(e1b, sa[1][15])
+        PVF(3, 0, 3, pb, pa[3][0], e0a, e0b, e1a, sa[1][10], e1b, sa[1][11])
+        QKF(1, 3, 1, sb, pa[3][1], e1a, e1b, e0a, sa[1][12], e0b, sa[1][13])
+        PVF(3, 1, 3, pb, pa[3][2], e0a, e0b, e1a, sa[1][14], e1b, sa[1][15])
         LSM(3, 3, pb)
         stamp(0);
         // ---- step B: QK(jt, 2) -> sa, exp(sb) -> pb; the tile boundary; PV(jt, 0) from pa
         QKM(2, 0, 0, sa)
         MASKB(1, sb)
-        CVT(pa[3][3], e1a, e1b)
-        EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
+        CVT(pa[3][3], e1a, e1b) EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
         RDV(3)
-        QKM(2, 0, 1, sa)
-        CVT(pb[0][0], e0a, e0b)
-        EXP(e1a, sb[0][2]) EXP(e1b, sb[0][3])
-        QKM(2, 1, 0, sa)
-        CVT(pb[0][1], e1a, e1b)
-        EXP(e0a, sb[0][4]) EXP(e0b, sb[0][5])
-        QKM(2, 1, 1, sa)
-        CVT(pb[0][2], e0a, e0b)
-        EXP(e1a, sb[0][6]) EXP(e1b, sb[0][7])
+        QKF0(2, 0, 1, sa, pb[0][0], e0a, e0b, e1a, sb[0][2], e1b, sb[0][3])
+        QKF(2, 1, 0, sa, pb[0][1], e1a, e1b, e0a, sb[0][4], e0b, sb[0][5])
+        QKF(2, 1, 1, sa, pb[0][2], e0a, e0b, e1a, sb[0][6], e1b, sb[0][7])
         BOUNDARY()
         LGKM0()
-        PVM(0, 0, 0, pa)
-        CVT(pb[0][3], e1a, e1b)
-        EXP(e0a, sb[0][8]) EXP(e0b, sb[0][9])
-        PVM(0, 1, 0, pa)
-        CVT(pb[1][0], e0a, e0b)
-        EXP(e1a, sb[0][10]) EXP(e1b, sb[0][11])
+        PVF(0, 0, 0, pa, pb[0][3], e1a, e1b, e0a, sb[0][8], e0b, sb[0][9])
+        PVF(0, 1, 0, pa, pb[1][0], e0a, e0b, e1a, sb[0][10], e1b, sb[0][11])
         LSM(0, 0, pa)
-        QKM(2, 2, 0, sa)
-        CVT(pb[1][1], e1a, e1b)
-        EXP(e0a, sb[0][12]) EXP(e0b, sb[0][13])
-        PVM(0, 0, 1, pa)
-        CVT(pb[1][2], e0a, e0b)
-        EXP(e1a, sb[0][14]) EXP(e1b, sb[0][15])
-        QKM(2, 2, 1, sa)
-        CVT(pb[1][3], e1a, e1b)
-        EXP(e0a, sb[1][0]) EXP(e0b, sb[1][1])
-        PVM(0, 1, 1, pa)
-        CVT(pb[2][0], e0a, e0b)
-        EXP(e1a, sb[1][2]) EXP(e1b, sb[1][3])
+        QKF(2, 2, 0, sa, pb[1][1], e1a, e1b, e0a, sb[0][12], e0b, sb[0][13])
+        PVF(0, 0, 1, pa, pb[1][2], e0a, e0b, e1a, sb[0][14], e1b, sb[0][15])
+        QKF(2, 2, 1, sa, pb[1][3], e1a, e1b, e0a, sb[1][0], e0b, sb[1][1])
+        PVF(0, 1, 1, pa, pb[2][0], e0a, e0b, e1a, sb[1][2], e1b, sb[1][3])
         LSM(0, 1, pa)
-        QKM(2, 3, 0, sa)
-        CVT(pb[2][1], e1a, e1b)
-        EXP(e0a, sb[1][4]) EXP(e0b, sb[1][5])
-        PVM(0, 0, 2, pa)
-        CVT(pb[2][2], e0a, e0b)
-        EXP(e1a, sb[1][6]) EXP(e1b, sb[1][7])
-        QKM(2, 3, 1, sa)
-        CVT(pb[2][3], e1a, e1b)
-        EXP(e0a, sb[1][8]) EXP(e0b, sb[1][9])
-        PVM(0, 1, 2, pa)
-        CVT(pb[3][0], e0a, e0b)
-        EXP(e1a, sb[1][10]) EXP(e1b, sb[1][11])
+        QKF(2, 3, 0, sa, pb[2][1], e1a, e1b, e0a, sb[1][4], e0b, sb[1][5])
+        PVF(0, 0, 2, pa, pb[2][2], e0a, e0b, e1a, sb[1][6], e1b, sb[1][7])
+        QKF(2, 3, 1, sa, pb[2][3], e1a, e1b, e0a, sb[1][8], e0b, sb[1][9])
+        PVF(0, 1, 2, pa, pb[3][0], e0a, e0b, e1a, sb[1][10], e1b, sb[1][11])
         LSM(0, 2, pa)
-        PVM(0, 0, 3, pa)
-        CVT(pb[3][1], e1a, e1b)
-        EXP(e0a, sb[1][12]) EXP(e0b, sb[1][13])
-        PVM(0, 1, 3, pa)
-        CVT(pb[3][2], e0a, e0b)
-        EXP(e1a, sb[1][14]) EXP(e1b, sb[1][15])
+        PVF(0, 0, 3, pa, pb[3][1], e1a, e1b, e0a, sb[1][12], e0b, sb[1][13])
+        PVF(0, 1, 3, pa, pb[3][2], e0a, e0b, e1a, sb[1][14], e1b, sb[1][15])
         LSM(0, 3, pa)
         stamp(1);
         // ---- step C: QK(jt, 3) -> sb, PV(jt, 1) from pb, exp(sa) -> pa; the K fragments of tile jt + 1 k-slice by k-slice
         //      behind the QK MFMAs that read the old ones
         QKM(3, 0, 0, sb)
         MASKB(2, sa)
-        CVT(pb[3][3], e1a, e1b)
-        EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
-        PVM(1, 0, 0, pb)
-        CVT(pa[0][0], e0a, e0b)
-        EXP(e1a, sa[0][2]) EXP(e1b, sa[0][3])
-        QKM(3, 0, 1, sb)
-        CVT(pa[0][1], e1a, e1b)
-        EXP(e0a, sa[0][4]) EXP(e0b, sa[0][5])
-        PVM(1, 1, 0, pb)
-        CVT(pa[0][2], e0a, e0b)
-        EXP(e1a, sa[0][6]) EXP(e1b, sa[0][7])
+        CVT(pb[3][3], e1a, e1b) EXP(e0a, sa[0][0]) EXP(e0b, sa[0][1])
+        PVF(1, 0, 0, pb, pa[0][0], e0a, e0b, e1a, sa[0][2], e1b, sa[0][3])
+        QKF0(3, 0, 1, sb, pa[0][1], e1a, e1b, e0a, sa[0][4], e0b, sa[0][5])
+        PVF(1, 1, 0, pb, pa[0][2], e0a, e0b, e1a, sa[0][6], e1b, sa[0][7])
         RDK(0)
         LSM(1, 0, pb)
-        QKM(3, 1, 0, sb)
-        CVT(pa[0][3], e1a, e1b)
-        EXP(e0a, sa[0][8]) EXP(e0b, sa[0][9])
-        PVM(1, 0, 1, pb)
-        CVT(pa[1][0], e0a, e0b)
-        EXP(e1a, sa[0][10]) EXP(e1b, sa[0][11])
-        QKM(3, 1, 1, sb)
-        CVT(pa[1][1], e1a, e1b)
-        EXP(e0a, sa[0][12]) EXP(e0b, sa[0][13])
-        PVM(1, 1, 1, pb)
-        CVT(pa[1][2], e0a, e0b)
-        EXP(e1a, sa[0][14]) EXP(e1b, sa[0][15])
+        QKF(3, 1, 0, sb, pa[0][3], e1a, e1b, e0a, sa[0][8], e0b, sa[0][9])
+        PVF(1, 0, 1, pb, pa[1][0], e0a, e0b, e1a, sa[0][10], e1b, sa[0][11])
+        QKF(3, 1, 1, sb, pa[1][1], e1a, e1b, e0a, sa[0][12], e0b, sa[0][13])
+        PVF(1, 1, 1, pb, pa[1][2], e0a, e0b, e1a, sa[0][14], e1b, sa[0][15])
         RDK(1)
         LSM(1, 1, pb)
-        QKM(3, 2, 0, sb)
-        CVT(pa[1][3], e1a, e1b)
-        EXP(e0a, sa[1][0]) EXP(e0b, sa[1][1])
-        PVM(1, 0, 2, pb)
-        CVT(pa[2][0], e0a, e0b)
-        EXP(e1a, sa[1][2]) EXP(e1b, sa[1][3])
-        QKM(3, 2, 1, sb)
-        CVT(pa[2][1], e1a, e1b)
-        EXP(e0a, sa[1][4]) EXP(e0b, sa[1][5])
-        PVM(1, 1, 2, pb)
-        CVT(pa[2][2], e0a, e0b)
-        EXP(e1a, sa[1][6]) EXP(e1b, sa[1][7])
+        QKF(3, 2, 0, sb, pa[1][3], e1a, e1b, e0a, sa[1][0], e0b, sa[1][1])
+        PVF(1, 0, 2, pb, pa[2][0], e0a, e0b, e1a, sa[1][2], e1b, sa[1][3])
+        QKF(3, 2, 1, sb, pa[2][1], e1a, e1b, e0a, sa[1][4], e0b, sa[1][5])
+        PVF(1, 1, 2, pb, pa[2][2], e0a, e0b, e1a, sa[1][6], e1b, sa[1][7])
         RDK(2)
         LSM(1, 2, pb)
-        QKM(3, 3, 0, sb)
-        CVT(pa[2][3], e1a, e1b)
-        EXP(e0a, sa[1][8]) EXP(e0b, sa[1][9])
-        PVM(1, 0, 3, pb)
-        CVT(pa[3][0], e0a, e0b)
-        EXP(e1a, sa[1][10]) EXP(e1b, sa[1][11])
-        QKM(3, 3, 1, sb)
-        CVT(pa[3][1], e1a, e1b)
-        EXP(e0a, sa[1][12]) EXP(e0b, sa[1][13])
-        PVM(1, 1, 3, pb)
-        CVT(pa[3][2], e0a, e0b)
-        EXP(e1a, sa[1][14]) EXP(e1b, sa[1][15])
+        QKF(3, 3, 0, sb, pa[2][3], e1a, e1b, e0a, sa[1][8], e0b, sa[1][9])
+        PVF(1, 0, 3, pb, pa[3][0], e0a, e0b, e1a, sa[1][10], e1b, sa[1][11])
+        QKF(3, 3, 1, sb, pa[3][1], e1a, e1b, e0a, sa[1][12], e0b, sa[1][13])
+        PVF(1, 1, 3, pb, pa[3][2], e0a, e0b, e1a, sa[1][14], e1b, sa[1][15])
         LSM(1, 3, pb)
         RDK(3)
         stamp(2);
         // ---- step D: PV(jt, 2) from pa, QK(jt + 1, 0) -> sa (on the last tile: of stale K fragments, never read), exp(sb) -> pb
         PVM(2, 0, 0, pa)
         MASKB(3, sb)
-        CVT(pa[3][3], e1a, e1b)
-        EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
-        PVM(2, 1, 0, pa)
-        CVT(pb[0][0], e0a, e0b)
-        EXP(e1a, sb[0][2]) EXP(e1b, sb[0][3])
+        CVT(pa[3][3], e1a, e1b) EXP(e0a, sb[0][0]) EXP(e0b, sb[0][1])
+        PVF(2, 1, 0, pa, pb[0][0], e0a, e0b, e1a, sb[0][2], e1b, sb[0][3])
         LSM(2, 0, pa)
         asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-        QKM(0, 0, 0, sa)
-        CVT(pb[0][1], e1a, e1b)
-        EXP(e0a, sb[0][4]) EXP(e0b, sb[0][5])
-        QKM(0, 0, 1, sa)
-        CVT(pb[0][2], e0a, e0b)
-        EXP(e1a, sb[0][6]) EXP(e1b, sb[0][7])
-        QKM(0, 1, 0, sa)
-        CVT(pb[0][3], e1a, e1b)
-        EXP(e0a, sb[0][8]) EXP(e0b, sb[0][9])
-        PVM(2, 0, 1, pa)
-        CVT(pb[1][0], e0a, e0b)
-        EXP(e1a, sb[0][10]) EXP(e1b, sb[0][11])
-        QKM(0, 1, 1, sa)
-        CVT(pb[1][1], e1a, e1b)
-        EXP(e0a, sb[0][12]) EXP(e0b, sb[0][13])
-        PVM(2, 1, 1, pa)
-        CVT(pb[1][2], e0a, e0b)
-        EXP(e1a, sb[0][14]) EXP(e1b, sb[0][15])
+        QKF0(0, 0, 0, sa, pb[0][1], e1a, e1b, e0a, sb[0][4], e0b, sb[0][5])
+        QKF0(0, 0, 1, sa, pb[0][2], e0a, e0b, e1a, sb[0][6], e1b, sb[0][7])
+        QKF(0, 1, 0, sa, pb[0][3], e1a, e1b, e0a, sb[0][8], e0b, sb[0][9])
+        PVF(2, 0, 1, pa, pb[1][0], e0a, e0b, e1a, sb[0][10], e1b, sb[0][11])
+        QKF(0, 1, 1, sa, pb[1][1], e1a, e1b, e0a, sb[0][12], e0b, sb[0][13])
+        PVF(2, 1, 1, pa, pb[1][2], e0a, e0b, e1a, sb[0][14], e1b, sb[0][15])
         LSM(2, 1, pa)
-        QKM(0, 2, 0, sa)
-        CVT(pb[1][3], e1a, e1b)
-        EXP(e0a, sb[1][0]) EXP(e0b, sb[1][1])
-        PVM(2, 0, 2, pa)
-        CVT(pb[2][0], e0a, e0b)
-        EXP(e1a, sb[1][2]) EXP(e1b, sb[1][3])
-        QKM(0, 2, 1, sa)
-        CVT(pb[2][1], e1a, e1b)
-        EXP(e0a, sb[1][4]) EXP(e0b, sb[1][5])
-        PVM(2, 1, 2, pa)
-        CVT(pb[2][2], e0a, e0b)
-        EXP(e1a, sb[1][6]) EXP(e1b, sb[1][7])
+        QKF(0, 2, 0, sa, pb[1][3], e1a, e1b, e0a, sb[1][0], e0b, sb[1][1])
+        PVF(2, 0, 2, pa, pb[2][0], e0a, e0b, e1a, sb[1][2], e1b, sb[1][3])
+        QKF(0, 2, 1, sa, pb[2][1], e1a, e1b, e0a, sb[1][4], e0b, sb[1][5])
+        PVF(2, 1, 2, pa, pb[2][2], e0a, e0b, e1a, sb[1][6], e1b, sb[1][7])
         LSM(2, 2, pa)
         LGKM0()
-        QKM(0, 3, 0, sa)
-        CVT(pb[2][3], e1a, e1b)
-        EXP(e0a, sb[1][8]) EXP(e0b, sb[1][9])
-        PVM(2, 0, 3, pa)
-        CVT(pb[3][0], e0a, e0b)
-        EXP(e1a, sb[1][10]) EXP(e1b, sb[1][11])
-        QKM(0, 3, 1, sa)
-        CVT(pb[3][1], e1a, e1b)
-        EXP(e0a, sb[1][12]) EXP(e0b, sb[1][13])
-        PVM(2, 1, 3, pa)
-        CVT(pb[3][2], e0a, e0b)
-        EXP(e1a, sb[1][14]) EXP(e1b, sb[1][15])
+        QKF(0, 3, 0, sa, pb[2][3], e1a, e1b, e0a, sb[1][8], e0b, sb[1][9])
+        PVF(2, 0, 3, pa, pb[3][0], e0a, e0b, e1a, sb[1][10], e1b, sb[1][11])
+        QKF(0, 3, 1, sa, pb[3][1], e1a, e1b, e0a, sb[1][12], e0b, sb[1][13])
+        PVF(2, 1, 3, pa, pb[3][2], e0a, e0b, e1a, sb[1][14], e1b, sb[1][15])
         LSM(2, 3, pa)
         stamp(3);
         // GENERATED BODY END
@@ -751,6 +582,11 @@ __global__ __launch_bounds__(256, 1) void attn128_pipe_kernel(const AArgs p) {
 #undef QKM
 #undef PVM
 #undef LSM
+#undef QKF0
+#undef QKF
+#undef PVF
+#undef PQ_Q_OUT
+#undef PQ_Q_IN
 #undef RDK
 #undef RDV
 #undef LGKM0

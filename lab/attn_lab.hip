@@ -503,7 +503,7 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((attn128_fast_kernel<true>), dim3(grid512), dim3(256), 2 * ABUF, st, a); }, true});
     vars.push_back({"attn128 pipe (hand-placed, 1 wave / SIMD) alone", [&] {
         hipLaunchKernelGGL((attn128_pipe_kernel<0, 0>), dim3(grid512), dim3(256), 3 * ABUF, st, a); }, true});
-    vars.push_back({"attn128 pipe, fillers in pairs, alone", [&] {
+    vars.push_back({"attn128 pipe, MFMA and quarter as separate statements, alone", [&] {
         hipLaunchKernelGGL((attn128_pipe_kernel<0, 5>), dim3(grid512), dim3(256), 3 * ABUF, st, a); }, true});
     vars.push_back({"attn64 stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 2>), dim3(grid64), dim3(256), SM64, st, a); }, true});
     vars.push_back({"attn64 FAST stamped", [&] { hipLaunchKernelGGL((attn64_kernel<2, 3>), dim3(grid64), dim3(256), SM64, st, a); }, false});
@@ -613,7 +613,7 @@ int main(int argc, char** argv) {
     }
     for (int sv = 0; sv < 7; ++sv) {
         CK(hipMemset(d_dbg, 0, nwg_max * 4 * lab::NPH * 4));
-        const char* nm[7] = {"loop-stamped", "step-stamped", "step-stamped, NO V fragment reads", "step-stamped, NO barrier", "step-stamped, NO further DMA", "step-stamped, NO K fragment reads", "step-stamped, fillers in pairs"};
+        const char* nm[7] = {"loop-stamped", "step-stamped", "step-stamped, NO V fragment reads", "step-stamped, NO barrier", "step-stamped, NO further DMA", "step-stamped, NO K fragment reads", "step-stamped, separate statements"};
         switch (sv) {
             case 0: hipLaunchKernelGGL((attn128_pipe_kernel<1, 0>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;
             case 1: hipLaunchKernelGGL((attn128_pipe_kernel<2, 0>), dim3(grid512), dim3(256), 3 * ABUF, st, a); break;

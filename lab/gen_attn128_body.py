@@ -16,48 +16,48 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def gen(pair=False):
+def gen(fused=True):
     out = []
     emit = out.append
     state = {"prev": None, "t": 0}                 # previous quarter's destination word, temp pair in use
 
-    def filler(S, P, g, q):
+    def quarter_args(S, P, g, q):
+        """(cvt destination, cvt inputs, exp destinations and sources) of the next quarter; advances the temp pair"""
         t = state["t"]
-        if state["prev"] is not None:
-            pP, pg, pq = state["prev"]
-            emit(f"        CVT({pP}[{pg}][{pq}], e{1 - t}a, e{1 - t}b)")
-        else:
-            emit(f"        CVT(pb[3][3], e{1 - t}a, e{1 - t}b)          /* the last quarter of the previous tile's block 3 */")
-        emit(f"        EXP(e{t}a, {S}[{g >> 1}][{8 * (g & 1) + 2 * q}]) EXP(e{t}b, {S}[{g >> 1}][{8 * (g & 1) + 2 * q + 1}])")
+        pP, pg, pq = state["prev"] if state["prev"] is not None else ("pb", 3, 3)      # tile start: the previous tile's last quarter
+        args = (f"{pP}[{pg}][{pq}]", f"e{1 - t}a", f"e{1 - t}b", f"e{t}a", f"{S}[{g >> 1}][{8 * (g & 1) + 2 * q}]", f"e{t}b", f"{S}[{g >> 1}][{8 * (g & 1) + 2 * q + 1}]")
         state["prev"] = (P, g, q)
         state["t"] = 1 - t
+        return args
 
     def step(mf, S, P, maskx, extra=None):
-        """mf: the MFMA statements of the step in order (16 big ones, each followed by a quarter; LSM = row-sum MFMA, no quarter);
-        extra[n] = lines emitted after statement n (and its quarter), extra[-1] = lines before statement 0"""
+        """mf: the MFMA statements of the step in order (16 big ones, each with a quarter; LSM = row-sum MFMA, no quarter);
+        extra[n] = lines emitted after statement n (and its quarter)"""
         extra = extra or {}
         quarters = [(g, q) for g in range(4) for q in range(4)]
         qi = 0
-        for ln in extra.get(-1, []):
-            emit("        " + ln)
-        owed = 0
         for n, m in enumerate(mf):
-            emit("        " + m)
-            if n == 0:
-                emit(f"        MASKB({maskx}, {S})")
-            if not m.startswith("LSM"):
-                owed += 1
-            if owed and (not pair or owed == 2 or n == 0 or n == len(mf) - 1 or n in extra):
-                # (pair mode: the quarters of two MFMAs go behind the second one; a step's first statement keeps its own quarter
-                # in front of the mask code, statements with extras flush)
-                for _ in range(owed):
-                    g, q = quarters[qi]
-                    qi += 1
-                    filler(S, P, g, q)
-                owed = 0
+            big = not m.startswith("LSM")
+            if big:
+                g, q = quarters[qi]
+                qi += 1
+                w, ca, cb, ea, xa, eb, xb = quarter_args(S, P, g, q)
+            if big and fused and n > 0:
+                # QKM(x, ks, i, s) -> QKF(x, ks, i, s, quarter...), PVM -> PVF; a leading "KWAIT"-like prefix stays in front
+                head, call = m.rsplit(" ", 1) if " " in m and not m.startswith(("QKM(", "PVM(")) else ("", m)
+                ks0 = call.startswith("QKM(") and call.split(",")[1].strip() == "0"
+                call = call.replace("QKM(", "QKF0(" if ks0 else "QKF(").replace("PVM(", "PVF(")
+                assert call.endswith(")")
+                emit("        " + (head + " " if head else "") + call[:-1] + f", {w}, {ca}, {cb}, {ea}, {xa}, {eb}, {xb})")
+            else:
+                emit("        " + m)
+                if n == 0:
+                    emit(f"        MASKB({maskx}, {S})")            # (the step's first quarter reads S: the mask goes in front of it)
+                if big:
+                    emit(f"        CVT({w}, {ca}, {cb}) EXP({ea}, {xa}) EXP({eb}, {xb})")
             for ln in extra.get(n, []):
                 emit("        " + ln)
-        assert qi == 16 and owed == 0, (qi, owed)
+        assert qi == 16, qi
 
     def qk(x, ks, i, s):
         return f"QKM({x}, {ks}, {i}, {s})"
@@ -95,6 +95,7 @@ def gen(pair=False):
     emit("        stamp(2);")
     emit("        // ---- step D: PV(jt, 2) from pa, QK(jt + 1, 0) -> sa (on the last tile: of stale K fragments, never read), exp(sb) -> pb")
     mD = [pv(2, 0, 0, "pa"), pv(2, 1, 0, "pa"), ls(2, 0, "pa"), qk(0, 0, 0, "sa"), qk(0, 0, 1, "sa")]
+    assert not any(" " in m.split("(")[0] for m in mD)
     for ks in range(1, 4):
         mD += [qk(0, ks, 0, "sa"), pv(2, 0, ks, "pa"), qk(0, ks, 1, "sa"), pv(2, 1, ks, "pa"), ls(2, ks, "pa")]
     # k-slices 0 .. 2 were requested long ago; k-slice 3 (the last two reads) a moment ago
@@ -135,7 +136,7 @@ def main():
     src = src[:a] + "// GENERATED BODY BEGIN (lab/gen_attn128_body.py)\n" + gen() + "        " + src[b:]
     a = src.index("// GENERATED PAIR BODY BEGIN")
     b = src.index("// GENERATED PAIR BODY END")
-    src = src[:a] + "// GENERATED PAIR BODY BEGIN (lab/gen_attn128_body.py, pair mode)\n" + gen(pair=True) + "        " + src[b:]
+    src = src[:a] + "// GENERATED PAIR BODY BEGIN (lab/gen_attn128_body.py, separate statements)\n" + gen(fused=False) + "        " + src[b:]
     open(path, "w").write(src)
 
 
