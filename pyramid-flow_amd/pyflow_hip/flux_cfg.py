@@ -14,6 +14,7 @@ walk depends on the row count).  Selected with init_sequence_parallel_group(...,
 import torch
 
 from .flux import FluxEngine
+from .sp import pair_gather
 
 
 class FluxEngineCFG(FluxEngine):
@@ -52,8 +53,5 @@ class FluxEngineCFG(FluxEngine):
         assert len(timesteps) == 2 and shared_clips, "guidance parallelism: the CFG duplicate of one latent (pipeline.py:747)"
         v = super().forward_tokens(plan, clips, timesteps[r:r + 1], self._my_row(pooled), ctx, True, debug)   # [1, n_cur, npad]
         n = v.shape[1] * v.shape[2]
-        out = self._buf("vtok_pair", 2 * n, torch.float32)
-        out[:2 * n].zero_()
-        out[r * n:(r + 1) * n].copy_(v.reshape(-1))
-        self.comm.all_reduce(out[:2 * n])
-        return out[:2 * n].view(2, v.shape[1], v.shape[2])
+        out = self._buf("vtok_pair", 2 * n, torch.float32)[:2 * n]
+        return pair_gather(self.comm, v, out).view(2, v.shape[1], v.shape[2])

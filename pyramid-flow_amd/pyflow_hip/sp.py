@@ -266,6 +266,20 @@ _SP_PROC_NUM = None
 _GUIDANCE_PARALLEL = False
 
 
+def pair_gather(comm, mine, out):
+    """Guidance parallelism (flux_cfg.py): both ranks of a world of 2 end with `out` = [rank 0's `mine` | rank 1's `mine`].
+    `out` (2 x mine.numel() elements, same dtype / device) is zeroed, this rank's slot filled and the buffer summed over the
+    ranks: every element is ONE value + one zero, so the result is exact and identical on both ranks in any reduction order
+    (an all-gather in effect, through the all-reduce every communicator backend of SPComm already has)."""
+    n = mine.numel()
+    assert comm.world == 2 and out.numel() == 2 * n and out.dtype == mine.dtype
+    flat = out.view(-1)
+    flat.zero_()
+    flat[comm.rank * n:(comm.rank + 1) * n].copy_(mine.reshape(-1))
+    comm.all_reduce(flat)
+    return out
+
+
 def init_sequence_parallel_group(args=None, sp_group_size=None, native=False, guidance_parallel=False):
     """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world) over the
     first `args.sp_proc_num` processes (-1 / absent = all).  A process outside every group stays un-initialised.

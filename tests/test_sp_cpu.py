@@ -131,3 +131,40 @@ def test_context_parallel_helpers_over_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert all(all(r[1:]) for r in res), res
+
+
+def _pair_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyflow_hip.sp import init_sequence_parallel_group, is_guidance_parallel, pair_gather
+    comm = init_sequence_parallel_group(sp_group_size=world, guidance_parallel=True)
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(1, 37, 64, generator=g)
+    mine[0, 0, 0] = -0.0                                   # the sum with the other rank's zero must keep every value's bits ...
+    mine[0, 0, 1] = 1e-42                                  # ... (a denormal; -0.0 + 0.0 = +0.0 compares equal)
+    out = torch.full((2 * mine.numel(),), float("nan"))    # stale contents of the reused buffer
+    both = pair_gather(comm, mine, out).view(2, 37, 64)
+    exp = torch.stack([torch.randn(1, 37, 64, generator=torch.Generator().manual_seed(100 + r))[0] for r in range(2)])
+    exp[:, 0, 0] = 0.0
+    exp[:, 0, 1] = 1e-42
+    q.put((rank, is_guidance_parallel(), torch.equal(both, exp), both.data_ptr() == out.data_ptr()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_guidance_pair_gather_over_gloo():
+    """the one exchange of the guidance-parallel engine (flux_cfg.py: FluxEngineCFG.forward_tokens): each rank's velocity
+    tokens into a replicated [2, n_cur, 64] buffer -- exact, identical on both ranks, in place in the caller's buffer"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, True, True), (1, True, True, True)], res
