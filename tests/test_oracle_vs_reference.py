@@ -385,3 +385,31 @@ def test_batch_fixture_is_the_references_and_rows_are_independent(ref, tmp_path,
     fresh = torch.load(os.path.join(str(tmp_path), "generate_tiny_latents_batch2.pt"))
     assert torch.equal(fresh["latents"], committed["latents"])
     assert fresh["latents"].shape[0] == 2 and not torch.equal(fresh["latents"][0], fresh["latents"][1])
+
+
+def test_reference_cfg_pair_equals_two_single_row_forwards(ref):
+    """The premise of guidance parallelism (pyflow_hip/flux_cfg.py: one classifier-free-guidance branch per rank): in the
+    UNMODIFIED reference the two rows of the `torch.cat([latents] * 2)` forward (pyramid_dit_for_video_gen_pipeline.py:747-776)
+    do not interact -- every op of flux:392-542 is per sample, the padded-text mask included -- so row r of the batch-of-2
+    forward equals the batch-of-1 forward of prompt row r (fp32, CPU; up to the summation order of batched matmuls)."""
+    from oracle import ref_harness as rh
+    m = rh.build_ref_dit()
+    g = torch.Generator().manual_seed(11)
+    one = [torch.randn(1, 16, 2, 4, 8, generator=g), torch.randn(1, 16, 1, 8, 16, generator=g),
+           torch.randn(1, 16, 1, 16, 32, generator=g), torch.randn(1, 16, 1, 16, 32, generator=g)]
+    clips = [c.repeat(2, 1, 1, 1, 1) for c in one]                      # the CFG duplicate of one latent
+    enc = torch.randn(2, 16, 32, generator=g)
+    mask = torch.zeros(2, 16, dtype=torch.long)
+    mask[0, :5] = 1
+    mask[1, :12] = 1
+    pooled = torch.randn(2, 16, generator=g)
+    t = torch.tensor([512.0, 512.0])
+    with torch.no_grad():
+        both = m(sample=[clips], encoder_hidden_states=enc, encoder_attention_mask=mask, pooled_projections=pooled,
+                 timestep_ratio=t)[0]
+        for r in range(2):
+            alone = m(sample=[[c.clone() for c in one]], encoder_hidden_states=enc[r:r + 1], encoder_attention_mask=mask[r:r + 1],
+                      pooled_projections=pooled[r:r + 1], timestep_ratio=t[r:r + 1])[0]
+            assert alone.shape == both[r:r + 1].shape
+            assert (alone - both[r:r + 1]).abs().max().item() < 2e-5 * max(1.0, both.abs().max().item())
+    assert (both[0] - both[1]).abs().max().item() > 1e-3                # the two prompts do give two different velocities
