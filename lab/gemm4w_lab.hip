@@ -33,12 +33,15 @@ namespace {
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int BUF = 65536;                 // one LDS buffer: A rows [0, 32 KiB), W rows [32 KiB, 64 KiB)
+constexpr int BUF = 65536;                 // one LDS buffer = 32 KiB of A rows + 32 KiB of W rows
 
 // VAR (timing experiments, wrong results): 1 no LDS writes, 2 no global loads, 3 no fragment reads, 4 no barrier
-template <int STAMP, int VAR = 0>
+// PERSIST: one workgroup per CU walks a list of output tiles (XCD x owns a contiguous chunk of the tile order, its workgroups take
+// the chunk's tiles round-robin, as gemm8p does); the operand stream -- global loads three K-tiles ahead of the MFMAs, LDS writes
+// one ahead -- runs on ACROSS tile boundaries, so that only the epilogue itself (accumulator reads, stores) is not under MFMAs.
+template <int STAMP, int VAR = 0, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C,
-                                                        int M, int N, int K, int lda, int ldw, int ldc, unsigned* dbg) {
+                                                        int M, int N, int K, int lda, int ldw, int ldc, unsigned* dbg, int stagger = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     asm volatile("" ::: "a255");                                        // the whole accumulator file is in use
     const int tid = threadIdx.x, lane = tid & 63;
@@ -46,12 +49,34 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int T = tiles_m * tiles_n;
-    const int t = xcd_remap(blockIdx.x, T);
-    // groups of 4 row tiles x all column tiles (neighbouring workgroups share operand panels)
-    const int GM = 4, gsz = GM * tiles_n, grp = t / gsz, first_m = grp * GM, gm = min(tiles_m - first_m, GM);
-    const int r_in = t - grp * gsz, tn = r_in / gm, tm = first_m + (r_in - tn * gm);
-    const int m0 = tm * BM, n0 = tn * BN;
     const int nk = K / BK;
+    int n_my = 1, n_max = 1, tile_first = 0, tile_step = 0;
+    if (PERSIST) {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, nslot = (nwg - xcd + 7) >> 3;
+        const int cq = T >> 3, cr = T & 7, cs = xcd * cq + min(xcd, cr), clen = cq + (xcd < cr ? 1 : 0);
+        n_my = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;
+        n_max = (clen + nslot - 1) / nslot;
+        tile_first = cs + slot;
+        tile_step = nslot;
+    } else {
+        tile_first = xcd_remap(blockIdx.x, T);
+    }
+    if (n_my == 0) return;
+    if (PERSIST && stagger > 0 && n_my < n_max) {          // (only workgroups with a tile less than the busiest: their wait is free)
+        // desynchronise the workgroups: all 256 of them reaching their epilogue together write 32 MB in one burst (12 000 cycles
+        // of stores per tile at ~3 TB/s aggregate); phase (slot % 8) / 8 of a tile time, waited out here
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned)stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+    // tile order: groups of 4 row tiles x all column tiles (neighbouring workgroups share operand panels)
+    auto tile_mn = [&](int seq, int& m0, int& n0) {
+        const int t = tile_first + seq * tile_step;
+        const int GM = 4, gsz = GM * tiles_n, grp = t / gsz, first_m = grp * GM, gm = min(tiles_m - first_m, GM);
+        const int r_in = t - grp * gsz, tn = r_in / gm, tm = first_m + (r_in - tn * gm);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
 
     // ---- global side: wave w loads rows (8 w + i) * 8 + (lane >> 3), i = 0..7, 16 bytes (lane & 7) of the K-tile's 128
     // raw buffer descriptors (base, stride 0, 2 GiB of records, dword format): wave-uniform, four SGPRs each
@@ -64,64 +89,103 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
         r[3] = 0x00020000;
         return r;
     };
-    i32x4_t srdA = make_srd(A + (long long)m0 * lda), srdW = make_srd(W + (long long)n0 * ldw);
+    i32x4_t srdA, srdW;
     unsigned voffA[8], voffW[8];
+    // the LOAD stream's position: output tile ld_seq, K-tile ld_kt of it (it runs three K-tiles ahead of the MFMAs)
+    int ld_seq = 0, ld_kt = 0;
+    auto setup_load_tile = [&](int seq) {
+        int m0, n0;
+        tile_mn(seq, m0, n0);
+        srdA = make_srd(A + (long long)m0 * lda);
+        srdW = make_srd(W + (long long)n0 * ldw);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (8 * wid + i) * 8 + (lane >> 3);
-        voffA[i] = (unsigned)(min(m0 + row, M - 1) - m0) * (unsigned)(lda * 2) + (lane & 7) * 16;
-        voffW[i] = (unsigned)(min(n0 + row, N - 1) - n0) * (unsigned)(ldw * 2) + (lane & 7) * 16;
-    }
+        for (int i = 0; i < 8; ++i) {
+            const int row = (8 * wid + i) * 8 + (ln >> 3);
+            voffA[i] = (unsigned)(min(m0 + row, M - 1) - m0) * (unsigned)(lda * 2) + (ln & 7) * 16;
+            voffW[i] = (unsigned)(min(n0 + row, N - 1) - n0) * (unsigned)(ldw * 2) + (ln & 7) * 16;
+        }
+    };
+    setup_load_tile(0);
     // ---- LDS side.  Writes: row = 8 j + (lane >> 3) with j = 8 w + i: chunk ^ ((row >> 1) & 7) = (lane & 7) ^ (4 (i & 1) + (lane >> 4))
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-    unsigned wrv[2][2];                    // [buffer][i & 1]; + i * 1024 (+ 32768 for W rows) as the instruction's offset
+    // LDS map: A rows of buffer 0 | A rows of buffer 1 | W rows of buffer 0 | W rows of buffer 1 (32 KiB each): the buffer index is
+    // part of the instructions' 16-bit offsets, not of the address registers
+    unsigned wrA[2], wrW[2];               // [i & 1]; + b * 32768 + i * 1024 as the instruction's offset
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-            wrv[b][par] = lds0 + b * BUF + wid * 8192 + (lane >> 3) * 128 + ((((lane & 7) ^ (4 * par + (lane >> 4))) & 7) << 4);
+    for (int par = 0; par < 2; ++par) {
+        wrA[par] = lds0 + wid * 8192 + (lane >> 3) * 128 + ((((lane & 7) ^ (4 * par + (lane >> 4))) & 7) << 4);
+        wrW[par] = wrA[par] + 65536;
+    }
     // Fragment reads (32x32x16 operand: lane -> row lane & 31, 16-byte chunk 2 ks + (lane >> 5) of the row's 128 bytes)
     const int frow = lane & 31, hi = lane >> 5, swz = (lane >> 1) & 7;
-    unsigned rdA[2][4], rdW[2][4];         // [buffer][k-step]; + block * 4096 as the instruction's offset
+    unsigned rdA[4], rdW[4];               // [k-step]; + b * 32768 + block * 4096 as the instruction's offset
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const unsigned f = (unsigned)(frow * 128 + (((2 * ks + hi) ^ swz) << 4));
-            rdA[b][ks] = lds0 + b * BUF + wr * 16384 + f;
-            rdW[b][ks] = lds0 + b * BUF + 32768 + wc * 16384 + f;
-        }
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned f = (unsigned)(frow * 128 + (((2 * ks + hi) ^ swz) << 4));
+        rdA[ks] = lds0 + wr * 16384 + f;
+        rdW[ks] = lds0 + 65536 + wc * 16384 + f;
+    }
 
     bf16x8_t fa[2][4], fb[2][4];           // fragment sets (k-step parity) x blocks
     u32x4_t st[2][16];                     // staging sets (tile parity) x loads (0..7 A rows, 8..15 W rows)
     unsigned kofs = 0;                     // byte offset of the K-tile the NEXT global loads fetch
 
+// every accumulator-file register, as a clobber list: the MFMA statements below name their accumulators in the asm text, which
+// the compiler cannot see -- with this list on each of them it cannot keep a value of its own in the accumulator file across
+// any of them (without it hipcc parked a zero vector and two spills in a0..a7 of the persistent instantiation).  On the MFMAs of
+// the main loop the list costs an s_nop in front of every one of them (+13 % cycles per K-tile): there it is left off, the list
+// stays on the statements of the epilogue, and gen_gemm4w_body.py --check is what guards the loop
+#define ALL_AGPRS \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+    "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+    "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+    "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+    "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+    "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 #define LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");
 #define VMC(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
 #define BARRIER() if (VAR != 4) __builtin_amdgcn_s_barrier();
 #define MFMA(JN, IM, FS)                                                                                                  \
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(16 * (4 * (JN) + (IM))), "n"(16 * (4 * (JN) + (IM)) + 15), \
                  "v"(fb[FS][JN]), "v"(fa[FS][IM]));
-#define RDA(BUFI, KS, BLK, FS) if (VAR != 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[FS][BLK]) : "v"(rdA[BUFI][KS]), "n"((BLK) * 4096));
-#define RDW(BUFI, KS, BLK, FS) if (VAR != 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[FS][BLK]) : "v"(rdW[BUFI][KS]), "n"((BLK) * 4096));
-#define WRA(BUFI, I) if (VAR != 1) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wrv[BUFI][(I) & 1]), "v"(st[BUFI][I]), "n"((I) * 1024) : "memory");
-#define WRW(BUFI, I) if (VAR != 1) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wrv[BUFI][(I) & 1]), "v"(st[BUFI][8 + (I)]), "n"(32768 + (I) * 1024) : "memory");
+#define RDA(BUFI, KS, BLK, FS) if (VAR != 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[FS][BLK]) : "v"(rdA[KS]), "n"((BUFI) * 32768 + (BLK) * 4096));
+#define RDW(BUFI, KS, BLK, FS) if (VAR != 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[FS][BLK]) : "v"(rdW[KS]), "n"((BUFI) * 32768 + (BLK) * 4096));
+#define WRA(BUFI, I) if (VAR != 1) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wrA[(I) & 1]), "v"(st[BUFI][I]), "n"((BUFI) * 32768 + (I) * 1024) : "memory");
+#define WRW(BUFI, I) if (VAR != 1) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wrW[(I) & 1]), "v"(st[BUFI][8 + (I)]), "n"((BUFI) * 32768 + (I) * 1024) : "memory");
 #define LDA(SET, I) if (VAR != 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(st[SET][I]) : "v"(voffA[I]), "s"(srdA), "s"(kofs) : "memory");
 #define LDW(SET, I) if (VAR != 2) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(st[SET][8 + (I)]) : "v"(voffW[I]), "s"(srdW), "s"(kofs) : "memory");
 
     // ---- accumulators = 0 (MFMAs of zero operands write the accumulator file without a register move)
-    {
-        bf16x8_t z;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.0f;
-        asm volatile("" : "+v"(z));
-#define ZERO(X) asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %2, 0" ::"n"(16 * (X)), "n"(16 * (X) + 15), "v"(z));
-        ZERO(0) ZERO(1) ZERO(2) ZERO(3) ZERO(4) ZERO(5) ZERO(6) ZERO(7) ZERO(8) ZERO(9) ZERO(10) ZERO(11) ZERO(12) ZERO(13) ZERO(14) ZERO(15)
-#undef ZERO
+    // (the zero operand is rebuilt where it is needed: four registers kept alive across the loop were what tipped hipcc into
+    // parking a value in a0..a3 -- the accumulator file belongs to the statements below, see gen_gemm4w_body.py --check)
+#define ZERO(X) asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %2, 0" ::"n"(16 * (X)), "n"(16 * (X) + 15), "v"(zfrag) : ALL_AGPRS);
+#define ZERO_ALL()                                                                                                              \
+    {                                                                                                                           \
+        bf16x8_t zfrag;                                                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) zfrag[e] = (bf16_t)0.0f;                                                  \
+        asm volatile("" : "+v"(zfrag));                                                                                         \
+        ZERO(0) ZERO(1) ZERO(2) ZERO(3) ZERO(4) ZERO(5) ZERO(6) ZERO(7) ZERO(8) ZERO(9) ZERO(10) ZERO(11) ZERO(12) ZERO(13) ZERO(14) ZERO(15) \
     }
+    ZERO_ALL()
     // ---- prologue: tiles 0 and 1 into the staging sets, tile 0 into LDS buffer 0, its first fragments
     // kofs = byte offset of the K-tile the next global loads fetch (tile 0, 1, 2 in the prologue, then tile kt + 3)
-#define KSTEP() kofs += 128;
+#define KSTEP()                                                                                          \
+    {                                                                                                    \
+        kofs += 128;                                                                                     \
+        if (++ld_kt == nk) { ld_kt = 0; kofs = 0; if (++ld_seq < n_my) setup_load_tile(ld_seq); }          \
+    }
     // GENERATED PROLOGUE BEGIN (lab/gen_gemm4w_body.py)
         LDA(0, 0)
         LDA(0, 1)
@@ -197,9 +261,325 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
         RDW(0, 0, 2, 0)
         RDW(0, 0, 3, 0)
         // GENERATED PROLOGUE END
-    // ---- main loop: nk even, >= 6.  Tile kt lives in LDS buffer kt & 1 and came through staging set kt & 1
+    // ---- epilogue: C^T blocks -> bf16 -> 16-byte stores (a lane pair exchanges halves: 8 consecutive columns each)
+    auto epilogue = [&](int seq) {
+    int m0, n0;
+    tile_mn(seq, m0, n0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int row_base = m0 + wr * 128 + frow, col_base = n0 + wc * 128 + 8 * hi;
+#define STORE_BLOCK(JN, IM)                                                                                               \
+    {                                                                                                                     \
+        float c[16];                                                                                                      \
+        asm volatile("v_accvgpr_read_b32 %0, a[%16]\n\tv_accvgpr_read_b32 %1, a[%17]\n\tv_accvgpr_read_b32 %2, a[%18]\n\tv_accvgpr_read_b32 %3, a[%19]\n\t" \
+                     "v_accvgpr_read_b32 %4, a[%20]\n\tv_accvgpr_read_b32 %5, a[%21]\n\tv_accvgpr_read_b32 %6, a[%22]\n\tv_accvgpr_read_b32 %7, a[%23]\n\t" \
+                     "v_accvgpr_read_b32 %8, a[%24]\n\tv_accvgpr_read_b32 %9, a[%25]\n\tv_accvgpr_read_b32 %10, a[%26]\n\tv_accvgpr_read_b32 %11, a[%27]\n\t" \
+                     "v_accvgpr_read_b32 %12, a[%28]\n\tv_accvgpr_read_b32 %13, a[%29]\n\tv_accvgpr_read_b32 %14, a[%30]\n\tv_accvgpr_read_b32 %15, a[%31]" \
+                     : "=v"(c[0]), "=v"(c[1]), "=v"(c[2]), "=v"(c[3]), "=v"(c[4]), "=v"(c[5]), "=v"(c[6]), "=v"(c[7]), "=v"(c[8]), "=v"(c[9]),   \
+                       "=v"(c[10]), "=v"(c[11]), "=v"(c[12]), "=v"(c[13]), "=v"(c[14]), "=v"(c[15])                                              \
+                     : "n"(16 * (4 * (JN) + (IM)) + 0), "n"(16 * (4 * (JN) + (IM)) + 1), "n"(16 * (4 * (JN) + (IM)) + 2), "n"(16 * (4 * (JN) + (IM)) + 3),     \
+                       "n"(16 * (4 * (JN) + (IM)) + 4), "n"(16 * (4 * (JN) + (IM)) + 5), "n"(16 * (4 * (JN) + (IM)) + 6), "n"(16 * (4 * (JN) + (IM)) + 7),     \
+                       "n"(16 * (4 * (JN) + (IM)) + 8), "n"(16 * (4 * (JN) + (IM)) + 9), "n"(16 * (4 * (JN) + (IM)) + 10), "n"(16 * (4 * (JN) + (IM)) + 11),   \
+                       "n"(16 * (4 * (JN) + (IM)) + 12), "n"(16 * (4 * (JN) + (IM)) + 13), "n"(16 * (4 * (JN) + (IM)) + 14), "n"(16 * (4 * (JN) + (IM)) + 15)  \
+                     : ALL_AGPRS);                                                                                        \
+        const int row = row_base + 32 * (IM);                                                                             \
+        _Pragma("unroll") for (int q8 = 0; q8 < 2; ++q8) {                                                                \
+            unsigned a0 = pack2(c[8 * q8 + 0], c[8 * q8 + 1]), a1 = pack2(c[8 * q8 + 2], c[8 * q8 + 3]);                  \
+            unsigned b0 = pack2(c[8 * q8 + 4], c[8 * q8 + 5]), b1 = pack2(c[8 * q8 + 6], c[8 * q8 + 7]);                  \
+            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);                                       \
+            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);                                       \
+            u32x4_t w;                                                                                                    \
+            w[0] = r0[0]; w[1] = r1[0]; w[2] = r0[1]; w[3] = r1[1];                                                       \
+            const int col = col_base + 32 * (JN) + 16 * q8;                                                               \
+            if (row < M && col < N) *(u32x4_t*)(C + (long long)row * ldc + col) = w;                                      \
+        }                                                                                                                 \
+    }
+    STORE_BLOCK(0, 0) STORE_BLOCK(0, 1) STORE_BLOCK(0, 2) STORE_BLOCK(0, 3) STORE_BLOCK(1, 0) STORE_BLOCK(1, 1) STORE_BLOCK(1, 2) STORE_BLOCK(1, 3)
+    STORE_BLOCK(2, 0) STORE_BLOCK(2, 1) STORE_BLOCK(2, 2) STORE_BLOCK(2, 3) STORE_BLOCK(3, 0) STORE_BLOCK(3, 1) STORE_BLOCK(3, 2) STORE_BLOCK(3, 3)
+#undef STORE_BLOCK
+    ZERO_ALL()
+    };
+    // ---- main loop: nk even, >= 4.  Stream K-tile g lives in LDS buffer g & 1 and came through staging set g & 1 (nk even: every
+    //      output tile starts in buffer 0)
     const unsigned t_loop0 = STAMP ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
-    for (int kt = 0; kt + 4 < nk; kt += 2) {
+    for (int seq = 0; seq < n_my; ++seq) {
+        const bool last = seq == n_my - 1;
+        const int jend = last ? nk - 4 : nk;
+        int j = 0;
+        if (seq > 0 && jend >= 2) {
+        // the two K-tiles behind an epilogue (vmcnt values count its 32 stores)
+        // GENERATED POST0 BEGIN (lab/gen_gemm4w_body.py)
+        LGKM(0)
+        MFMA(0, 0, 0)
+        RDW(0, 1, 0, 1)
+        MFMA(0, 1, 0)
+        RDA(0, 1, 0, 1)
+        MFMA(0, 2, 0)
+        RDA(0, 1, 1, 1)
+        MFMA(0, 3, 0)
+        RDA(0, 1, 2, 1)
+        MFMA(1, 0, 0)
+        RDA(0, 1, 3, 1)
+        MFMA(1, 1, 0)
+        RDW(0, 1, 1, 1)
+        MFMA(1, 2, 0)
+        RDW(0, 1, 2, 1)
+        MFMA(1, 3, 0)
+        RDW(0, 1, 3, 1)
+        MFMA(2, 0, 0)
+        VMC(63) WRA(1, 0)
+        MFMA(2, 1, 0)
+        VMC(62) WRA(1, 1)
+        MFMA(2, 2, 0)
+        VMC(61) WRA(1, 2)
+        MFMA(2, 3, 0)
+        VMC(60) WRA(1, 3)
+        MFMA(3, 0, 0)
+        VMC(59) WRA(1, 4)
+        MFMA(3, 1, 0)
+        VMC(58) WRA(1, 5)
+        MFMA(3, 2, 0)
+        KSTEP() LDA(1, 0)
+        MFMA(3, 3, 0)
+        LDA(1, 1)
+        LGKM(6)
+        MFMA(0, 0, 1)
+        RDW(0, 2, 0, 0)
+        MFMA(0, 1, 1)
+        RDA(0, 2, 0, 0)
+        MFMA(0, 2, 1)
+        RDA(0, 2, 1, 0)
+        MFMA(0, 3, 1)
+        RDA(0, 2, 2, 0)
+        MFMA(1, 0, 1)
+        RDA(0, 2, 3, 0)
+        MFMA(1, 1, 1)
+        RDW(0, 2, 1, 0)
+        MFMA(1, 2, 1)
+        RDW(0, 2, 2, 0)
+        MFMA(1, 3, 1)
+        RDW(0, 2, 3, 0)
+        MFMA(2, 0, 1)
+        VMC(59) WRA(1, 6)
+        MFMA(2, 1, 1)
+        VMC(58) WRA(1, 7)
+        MFMA(2, 2, 1)
+        VMC(57) WRW(1, 0)
+        MFMA(2, 3, 1)
+        VMC(56) WRW(1, 1)
+        MFMA(3, 0, 1)
+        VMC(55) WRW(1, 2)
+        MFMA(3, 1, 1)
+        LDA(1, 2)
+        MFMA(3, 2, 1)
+        LDA(1, 3)
+        MFMA(3, 3, 1)
+        LDA(1, 4)
+        LGKM(5)
+        MFMA(0, 0, 0)
+        RDW(0, 3, 0, 1)
+        MFMA(0, 1, 0)
+        RDA(0, 3, 0, 1)
+        MFMA(0, 2, 0)
+        RDA(0, 3, 1, 1)
+        MFMA(0, 3, 0)
+        RDA(0, 3, 2, 1)
+        MFMA(1, 0, 0)
+        RDA(0, 3, 3, 1)
+        MFMA(1, 1, 0)
+        RDW(0, 3, 1, 1)
+        MFMA(1, 2, 0)
+        RDW(0, 3, 2, 1)
+        MFMA(1, 3, 0)
+        RDW(0, 3, 3, 1)
+        MFMA(2, 0, 0)
+        VMC(57) WRW(1, 3)
+        MFMA(2, 1, 0)
+        VMC(56) WRW(1, 4)
+        MFMA(2, 2, 0)
+        VMC(55) WRW(1, 5)
+        MFMA(2, 3, 0)
+        VMC(54) WRW(1, 6)
+        MFMA(3, 0, 0)
+        VMC(53) WRW(1, 7)
+        MFMA(3, 1, 0)
+        LDA(1, 5)
+        MFMA(3, 2, 0)
+        LDA(1, 6)
+        MFMA(3, 3, 0)
+        LDA(1, 7)
+        LGKM(0) BARRIER()
+        LGKM(5)
+        MFMA(0, 0, 1)
+        RDW(1, 0, 0, 0)
+        MFMA(0, 1, 1)
+        RDA(1, 0, 0, 0)
+        MFMA(0, 2, 1)
+        RDA(1, 0, 1, 0)
+        MFMA(0, 3, 1)
+        RDA(1, 0, 2, 0)
+        MFMA(1, 0, 1)
+        RDA(1, 0, 3, 0)
+        MFMA(1, 1, 1)
+        RDW(1, 0, 1, 0)
+        MFMA(1, 2, 1)
+        RDW(1, 0, 2, 0)
+        MFMA(1, 3, 1)
+        RDW(1, 0, 3, 0)
+        MFMA(2, 0, 1)
+        LDW(1, 0)
+        MFMA(2, 1, 1)
+        LDW(1, 1)
+        MFMA(2, 2, 1)
+        LDW(1, 2)
+        MFMA(2, 3, 1)
+        LDW(1, 3)
+        MFMA(3, 0, 1)
+        LDW(1, 4)
+        MFMA(3, 1, 1)
+        LDW(1, 5)
+        MFMA(3, 2, 1)
+        LDW(1, 6)
+        MFMA(3, 3, 1)
+        LDW(1, 7)
+        // GENERATED POST0 END
+        // GENERATED POST1 BEGIN (lab/gen_gemm4w_body.py)
+        LGKM(0)
+        MFMA(0, 0, 0)
+        RDW(1, 1, 0, 1)
+        MFMA(0, 1, 0)
+        RDA(1, 1, 0, 1)
+        MFMA(0, 2, 0)
+        RDA(1, 1, 1, 1)
+        MFMA(0, 3, 0)
+        RDA(1, 1, 2, 1)
+        MFMA(1, 0, 0)
+        RDA(1, 1, 3, 1)
+        MFMA(1, 1, 0)
+        RDW(1, 1, 1, 1)
+        MFMA(1, 2, 0)
+        RDW(1, 1, 2, 1)
+        MFMA(1, 3, 0)
+        RDW(1, 1, 3, 1)
+        MFMA(2, 0, 0)
+        VMC(63) WRA(0, 0)
+        MFMA(2, 1, 0)
+        VMC(62) WRA(0, 1)
+        MFMA(2, 2, 0)
+        VMC(61) WRA(0, 2)
+        MFMA(2, 3, 0)
+        VMC(60) WRA(0, 3)
+        MFMA(3, 0, 0)
+        VMC(59) WRA(0, 4)
+        MFMA(3, 1, 0)
+        VMC(58) WRA(0, 5)
+        MFMA(3, 2, 0)
+        KSTEP() LDA(0, 0)
+        MFMA(3, 3, 0)
+        LDA(0, 1)
+        LGKM(6)
+        MFMA(0, 0, 1)
+        RDW(1, 2, 0, 0)
+        MFMA(0, 1, 1)
+        RDA(1, 2, 0, 0)
+        MFMA(0, 2, 1)
+        RDA(1, 2, 1, 0)
+        MFMA(0, 3, 1)
+        RDA(1, 2, 2, 0)
+        MFMA(1, 0, 1)
+        RDA(1, 2, 3, 0)
+        MFMA(1, 1, 1)
+        RDW(1, 2, 1, 0)
+        MFMA(1, 2, 1)
+        RDW(1, 2, 2, 0)
+        MFMA(1, 3, 1)
+        RDW(1, 2, 3, 0)
+        MFMA(2, 0, 1)
+        VMC(59) WRA(0, 6)
+        MFMA(2, 1, 1)
+        VMC(58) WRA(0, 7)
+        MFMA(2, 2, 1)
+        VMC(57) WRW(0, 0)
+        MFMA(2, 3, 1)
+        VMC(56) WRW(0, 1)
+        MFMA(3, 0, 1)
+        VMC(55) WRW(0, 2)
+        MFMA(3, 1, 1)
+        LDA(0, 2)
+        MFMA(3, 2, 1)
+        LDA(0, 3)
+        MFMA(3, 3, 1)
+        LDA(0, 4)
+        LGKM(5)
+        MFMA(0, 0, 0)
+        RDW(1, 3, 0, 1)
+        MFMA(0, 1, 0)
+        RDA(1, 3, 0, 1)
+        MFMA(0, 2, 0)
+        RDA(1, 3, 1, 1)
+        MFMA(0, 3, 0)
+        RDA(1, 3, 2, 1)
+        MFMA(1, 0, 0)
+        RDA(1, 3, 3, 1)
+        MFMA(1, 1, 0)
+        RDW(1, 3, 1, 1)
+        MFMA(1, 2, 0)
+        RDW(1, 3, 2, 1)
+        MFMA(1, 3, 0)
+        RDW(1, 3, 3, 1)
+        MFMA(2, 0, 0)
+        VMC(57) WRW(0, 3)
+        MFMA(2, 1, 0)
+        VMC(56) WRW(0, 4)
+        MFMA(2, 2, 0)
+        VMC(55) WRW(0, 5)
+        MFMA(2, 3, 0)
+        VMC(54) WRW(0, 6)
+        MFMA(3, 0, 0)
+        VMC(53) WRW(0, 7)
+        MFMA(3, 1, 0)
+        LDA(0, 5)
+        MFMA(3, 2, 0)
+        LDA(0, 6)
+        MFMA(3, 3, 0)
+        LDA(0, 7)
+        LGKM(0) BARRIER()
+        LGKM(5)
+        MFMA(0, 0, 1)
+        RDW(0, 0, 0, 0)
+        MFMA(0, 1, 1)
+        RDA(0, 0, 0, 0)
+        MFMA(0, 2, 1)
+        RDA(0, 0, 1, 0)
+        MFMA(0, 3, 1)
+        RDA(0, 0, 2, 0)
+        MFMA(1, 0, 1)
+        RDA(0, 0, 3, 0)
+        MFMA(1, 1, 1)
+        RDW(0, 0, 1, 0)
+        MFMA(1, 2, 1)
+        RDW(0, 0, 2, 0)
+        MFMA(1, 3, 1)
+        RDW(0, 0, 3, 0)
+        MFMA(2, 0, 1)
+        LDW(0, 0)
+        MFMA(2, 1, 1)
+        LDW(0, 1)
+        MFMA(2, 2, 1)
+        LDW(0, 2)
+        MFMA(2, 3, 1)
+        LDW(0, 3)
+        MFMA(3, 0, 1)
+        LDW(0, 4)
+        MFMA(3, 1, 1)
+        LDW(0, 5)
+        MFMA(3, 2, 1)
+        LDW(0, 6)
+        MFMA(3, 3, 1)
+        LDW(0, 7)
+        // GENERATED POST1 END
+            j = 2;
+        }
+        for (; j < jend; j += 2) {
         // GENERATED STEADY0 BEGIN (lab/gen_gemm4w_body.py)
         LGKM(0)
         MFMA(0, 0, 0)
@@ -470,9 +850,9 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
         MFMA(3, 3, 1)
         LDW(0, 7)
         // GENERATED STEADY1 END
-    }
-    {
-        // tile nk - 4 (steady, buffer 0), then the three tiles that request nothing further
+        }
+        if (last) {
+        // the stream's last four K-tiles: one more steady one, then the three that request nothing further
         // GENERATED STEADY0B BEGIN (lab/gen_gemm4w_body.py)
         LGKM(0)
         MFMA(0, 0, 0)
@@ -940,44 +1320,15 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16_t* __restrict
         MFMA(3, 2, 1)
         MFMA(3, 3, 1)
         // GENERATED TAIL1 END
+        }
+        epilogue(seq);
+    }
+    if (STAMP) {
+        const unsigned t_loop1 = (unsigned)__builtin_amdgcn_s_memtime();
+        if (lane == 0) { dbg[(blockIdx.x * 4 + wid) * 2] = t_loop1 - t_loop0; dbg[(blockIdx.x * 4 + wid) * 2 + 1] = (unsigned)(nk * n_my); }
     }
 #undef KSTEP
 
-    if (STAMP) {
-        const unsigned t_loop1 = (unsigned)__builtin_amdgcn_s_memtime();
-        if (lane == 0) { dbg[(blockIdx.x * 4 + wid) * 2] = t_loop1 - t_loop0; dbg[(blockIdx.x * 4 + wid) * 2 + 1] = (unsigned)nk; }
-    }
-    // ---- epilogue: C^T blocks -> bf16 -> 16-byte stores (a lane pair exchanges halves: 8 consecutive columns each)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    const int row_base = m0 + wr * 128 + frow, col_base = n0 + wc * 128 + 8 * hi;
-#define STORE_BLOCK(JN, IM)                                                                                               \
-    {                                                                                                                     \
-        float c[16];                                                                                                      \
-        asm volatile("v_accvgpr_read_b32 %0, a[%16]\n\tv_accvgpr_read_b32 %1, a[%17]\n\tv_accvgpr_read_b32 %2, a[%18]\n\tv_accvgpr_read_b32 %3, a[%19]\n\t" \
-                     "v_accvgpr_read_b32 %4, a[%20]\n\tv_accvgpr_read_b32 %5, a[%21]\n\tv_accvgpr_read_b32 %6, a[%22]\n\tv_accvgpr_read_b32 %7, a[%23]\n\t" \
-                     "v_accvgpr_read_b32 %8, a[%24]\n\tv_accvgpr_read_b32 %9, a[%25]\n\tv_accvgpr_read_b32 %10, a[%26]\n\tv_accvgpr_read_b32 %11, a[%27]\n\t" \
-                     "v_accvgpr_read_b32 %12, a[%28]\n\tv_accvgpr_read_b32 %13, a[%29]\n\tv_accvgpr_read_b32 %14, a[%30]\n\tv_accvgpr_read_b32 %15, a[%31]" \
-                     : "=v"(c[0]), "=v"(c[1]), "=v"(c[2]), "=v"(c[3]), "=v"(c[4]), "=v"(c[5]), "=v"(c[6]), "=v"(c[7]), "=v"(c[8]), "=v"(c[9]),   \
-                       "=v"(c[10]), "=v"(c[11]), "=v"(c[12]), "=v"(c[13]), "=v"(c[14]), "=v"(c[15])                                              \
-                     : "n"(16 * (4 * (JN) + (IM)) + 0), "n"(16 * (4 * (JN) + (IM)) + 1), "n"(16 * (4 * (JN) + (IM)) + 2), "n"(16 * (4 * (JN) + (IM)) + 3),     \
-                       "n"(16 * (4 * (JN) + (IM)) + 4), "n"(16 * (4 * (JN) + (IM)) + 5), "n"(16 * (4 * (JN) + (IM)) + 6), "n"(16 * (4 * (JN) + (IM)) + 7),     \
-                       "n"(16 * (4 * (JN) + (IM)) + 8), "n"(16 * (4 * (JN) + (IM)) + 9), "n"(16 * (4 * (JN) + (IM)) + 10), "n"(16 * (4 * (JN) + (IM)) + 11),   \
-                       "n"(16 * (4 * (JN) + (IM)) + 12), "n"(16 * (4 * (JN) + (IM)) + 13), "n"(16 * (4 * (JN) + (IM)) + 14), "n"(16 * (4 * (JN) + (IM)) + 15)); \
-        const int row = row_base + 32 * (IM);                                                                             \
-        _Pragma("unroll") for (int q8 = 0; q8 < 2; ++q8) {                                                                \
-            unsigned a0 = pack2(c[8 * q8 + 0], c[8 * q8 + 1]), a1 = pack2(c[8 * q8 + 2], c[8 * q8 + 3]);                  \
-            unsigned b0 = pack2(c[8 * q8 + 4], c[8 * q8 + 5]), b1 = pack2(c[8 * q8 + 6], c[8 * q8 + 7]);                  \
-            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);                                       \
-            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);                                       \
-            u32x4_t w;                                                                                                    \
-            w[0] = r0[0]; w[1] = r1[0]; w[2] = r0[1]; w[3] = r1[1];                                                       \
-            const int col = col_base + 32 * (JN) + 16 * q8;                                                               \
-            if (row < M && col < N) *(u32x4_t*)(C + (long long)row * ldc + col) = w;                                      \
-        }                                                                                                                 \
-    }
-    STORE_BLOCK(0, 0) STORE_BLOCK(0, 1) STORE_BLOCK(0, 2) STORE_BLOCK(0, 3) STORE_BLOCK(1, 0) STORE_BLOCK(1, 1) STORE_BLOCK(1, 2) STORE_BLOCK(1, 3)
-    STORE_BLOCK(2, 0) STORE_BLOCK(2, 1) STORE_BLOCK(2, 2) STORE_BLOCK(2, 3) STORE_BLOCK(3, 0) STORE_BLOCK(3, 1) STORE_BLOCK(3, 2) STORE_BLOCK(3, 3)
-#undef STORE_BLOCK
 }
 
 __global__ void fill_kernel(bf16_t* p, long long n, unsigned seed, float scale) {
@@ -993,13 +1344,15 @@ __global__ void fill_kernel(bf16_t* p, long long n, unsigned seed, float scale) 
 }  // namespace
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     struct Shape { int M, N, K; const char* what; };
     std::vector<Shape> shapes = {{30976, 7680, 1920, "MLP up  (N = 7680, K = 1920)"}, {30976, 1920, 7680, "MLP down (N = 1920, K = 7680)"},
                                  {30976, 5760, 1920, "K|V|Q   (N = 5760, K = 1920)"}, {30976, 1920, 1920, "attn out (N = 1920, K = 1920)"},
                                  {8192, 8192, 8192, "8192^3"}};
-    if (argc == 4) shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), "command line"}};
-    void* lib = dlopen("pyramid-flow_amd/libpyflow_hip.so", RTLD_NOW);
-    if (!lib) lib = dlopen("../pyramid-flow_amd/libpyflow_hip.so", RTLD_NOW);
+    if (argc >= 4) shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), "command line"}};
+    const int grid_override = argc >= 5 ? atoi(argv[4]) : 0;
+    void* lib = getenv("GEMM4W_NO_LIB") ? nullptr : dlopen("pyramid-flow_amd/libpyflow_hip.so", RTLD_NOW);
+    if (!lib && !getenv("GEMM4W_NO_LIB")) lib = dlopen("../pyramid-flow_amd/libpyflow_hip.so", RTLD_NOW);
     typedef int (*gemm_fn)(const pf_gemm_desc*, pf_stream_t);
     typedef long long (*ws_fn)(int, int, int, int);
     gemm_fn lib_gemm = lib ? (gemm_fn)dlsym(lib, "pf_gemm_bf16") : nullptr;
@@ -1012,6 +1365,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)gemm4w_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));
     CK(hipFuncSetAttribute((const void*)gemm4w_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));
     CK(hipFuncSetAttribute((const void*)gemm4w_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));
+    CK(hipFuncSetAttribute((const void*)gemm4w_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& s : shapes) {
@@ -1044,6 +1399,8 @@ int main(int argc, char** argv) {
             return ms[2];
         };
         printf("%s: M = %d\n", s.what, M);
+        CK(hipStreamSynchronize(st));
+        printf("   [operands filled]\n");
         float t_lib = 0;
         if (lib_gemm) {
             pf_gemm_desc d = {};
@@ -1052,18 +1409,15 @@ int main(int argc, char** argv) {
             const long long wsb = lib_ws ? lib_ws(M, 1, N, K) : 0;
             if (wsb > 0) { CK(hipMalloc(&ws, wsb)); d.workspace = ws; d.workspace_bytes = wsb; }
             if (lib_gemm(&d, st)) { printf("pf_gemm_bf16 failed\n"); return 1; }
+            CK(hipStreamSynchronize(st));
+            printf("   [library call returned]\n");
             t_lib = time_it([&] { lib_gemm(&d, st); }, 10);
             printf("   pf_gemm_bf16 (libpyflow_hip.so, gemm8p)      %.3f ms  %6.0f TFLOP/s\n", t_lib, flops / t_lib / 1e9);
             if (ws) CK(hipFree(ws));
         }
-        run4w();
-        CK(hipStreamSynchronize(st));
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { printf("gemm4w launch failed: %s\n", hipGetErrorString(le)); return 1; }
-        const float t4 = time_it(run4w, 10);
-        // compare with the library's result (different MFMA shape and summation order: bf16 rounding of nearly equal sums)
-        double rel = -1, mx = 0;
-        if (lib_gemm) {
+        auto compare = [&](double& rel, double& mx) {
+            rel = -1; mx = 0;
+            if (!lib_gemm) return;
             const size_t n = (size_t)M * N;
             std::vector<unsigned short> h1(n), h2(n);
             CK(hipMemcpy(h1.data(), C, n * 2, hipMemcpyDeviceToHost));
@@ -1074,22 +1428,48 @@ int main(int argc, char** argv) {
                 a.u = (unsigned)h1[i] << 16; b.u = (unsigned)h2[i] << 16;
                 const double dlt = (double)a.f - b.f;
                 num += dlt * dlt; den += (double)b.f * b.f;
-                if (std::fabs(dlt) > mx || dlt != dlt) mx = (dlt != dlt) ? 1e30 : std::fabs(dlt);
+                if (dlt != dlt) mx = 1e30; else if (std::fabs(dlt) > mx) mx = std::fabs(dlt);
             }
             rel = std::sqrt(num / (den + 1e-30));
-        }
-        printf("   gemm4w (4 waves, hand-placed, plain epilogue) %.3f ms  %6.0f TFLOP/s   vs library result: rel-L2 %.2e max-abs %.3g   (%d tiles = %.2f rounds)\n",
-               t4, flops / t4 / 1e9, rel, mx, T, T / 256.0);
+        };
+        printf("   [one launch per tile]\n");
+        run4w();
+        CK(hipStreamSynchronize(st));
+        double rel1, mx1;
+        compare(rel1, mx1);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { printf("gemm4w launch failed: %s\n", hipGetErrorString(le)); return 1; }
+        const float t4 = time_it(run4w, 10);
+        int ncu = 256;
+        { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); ncu = grid_override ? grid_override : pr.multiProcessorCount; }
+        auto run4wp = [&] { hipLaunchKernelGGL((gemm4w_kernel<0, 0, true>), dim3(ncu), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); };
+        CK(hipMemsetAsync(C, 0xff, (size_t)M * N * 2, st));
+        printf("   [persistent]\n");
+        run4wp();
+        CK(hipStreamSynchronize(st));
+        { hipError_t le2 = hipGetLastError(); if (le2 != hipSuccess) printf("persistent launch failed: %s\n", hipGetErrorString(le2)); }
+        double rel, mx;
+        compare(rel, mx);
+        const float t4p = time_it(run4wp, 10);
+        const int stag = (K / BK) * 2600 / 8;
+        auto run4ws = [&] { hipLaunchKernelGGL((gemm4w_kernel<0, 0, true>), dim3(ncu), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg, stag); };
+        const float t4s = time_it(run4ws, 10);
+        printf("   gemm4w, one launch per tile (plain epilogue)    %.3f ms  %6.0f TFLOP/s   vs library result: rel-L2 %.2e max-abs %.3g   (%d tiles = %.2f rounds)\n", t4, flops / t4 / 1e9, rel1, mx1, T, T / 256.0);
+        printf("   gemm4w, persistent (%d workgroups)              %.3f ms  %6.0f TFLOP/s   vs library result: rel-L2 %.2e max-abs %.3g\n", ncu, t4p, flops / t4p / 1e9, rel, mx);
+        printf("   gemm4w, persistent, starts staggered by slot %% 8    %.3f ms  %6.0f TFLOP/s\n", t4s, flops / t4s / 1e9);
         {
-            const char* nm[5] = {"", ", NO LDS writes", ", NO global loads", ", NO fragment reads", ", NO barrier"};
+            const char* nm[6] = {"", ", NO LDS writes", ", NO global loads", ", NO fragment reads", ", NO barrier", " persistent (incl. epilogues)"};
             printf("   gemm4w main loop, cycles per K-tile and wave (s_memtime; the matrix pipe needs 2048):");
-            for (int v = 0; v < 5; ++v) {
+            for (int v = 0; v < 6; ++v) {
+                if (v == 1) continue;         // (loads in flight into registers nobody reads: the compiler reuses them, e.g. for store addresses)
+                if (v == 5) CK(hipMemsetAsync(dbg, 0, (size_t)T * 4 * 2 * 4, st));
                 switch (v) {
                     case 0: hipLaunchKernelGGL((gemm4w_kernel<1, 0>), dim3(T), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
                     case 1: hipLaunchKernelGGL((gemm4w_kernel<1, 1>), dim3(T), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
                     case 2: hipLaunchKernelGGL((gemm4w_kernel<1, 2>), dim3(T), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
                     case 3: hipLaunchKernelGGL((gemm4w_kernel<1, 3>), dim3(T), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
-                    default: hipLaunchKernelGGL((gemm4w_kernel<1, 4>), dim3(T), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
+                    case 4: hipLaunchKernelGGL((gemm4w_kernel<1, 4>), dim3(T), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
+                    default: hipLaunchKernelGGL((gemm4w_kernel<1, 0, true>), dim3(ncu), dim3(256), 2 * BUF, st, A, W, C, M, N, K, K, K, N, dbg); break;
                 }
                 CK(hipStreamSynchronize(st));
                 std::vector<unsigned> hd((size_t)T * 8);

@@ -59,7 +59,9 @@ def tile_events(kt, nk):
     return ev
 
 
-def run_events(nk):
+def run_events(nk, stores_after=None):
+    """stores_after = stream K-tile index after which an epilogue issues its 32 global stores (they sit in the same in-order
+    vector-memory queue as the loads)"""
     ev = []
     for t in (0, 1):                          # prologue: tiles 0 and 1 requested, tile 0 written, tile 2 requested into the set
         for i in range(16):                   # tile 0 left, tile 0's first fragments read
@@ -76,6 +78,8 @@ def run_events(nk):
     for kt in range(nk):
         marks[kt] = len(ev)
         ev += tile_events(kt, nk)
+        if stores_after is not None and kt == stores_after:
+            ev += [("st", kt, i) for i in range(32)]
     marks[nk] = len(ev)
     return ev, marks
 
@@ -88,9 +92,11 @@ def annotate(ev):
     for n, e in enumerate(ev):
         if e[0] == "ld":
             vm.append((e[1], e[2]))
+        elif e[0] == "st":
+            vm.append(("store", e[1], e[2]))
         elif e[0] == "wr":
             pos = max(k for k, x in enumerate(vm) if x == (e[1], e[2]))
-            waits[n] = ("vm", len(vm) - 1 - pos)
+            waits[n] = ("vm", min(len(vm) - 1 - pos, 63))      # (6-bit counter: a smaller value only waits for more)
             lds.append(("wr", e[1], e[2]))
         elif e[0] == "rd":
             lds.append(("rd", e[6], e[7]))
@@ -125,10 +131,48 @@ def emit_range(ev, waits, lo, hi):
             out.append(f"        {step}{'LDA' if i < 8 else 'LDW'}({t & 1}, {i & 7})")
         elif e[0] == "barrier":
             out.append(f"        {pre}BARRIER()")
+        elif e[0] == "st":
+            pass
     return "\n".join(out) + "\n"
 
 
+def check(path):
+    """every instantiation of gemm4w_kernel in a .s file: no accumulator-file operand, v_accvgpr_* or scratch access outside
+    the hand-written statements (the compiler must not park values in registers the statements own)"""
+    src = open(path).read()
+    bad = 0
+    pos = 0
+    nker = 0
+    while True:
+        i = src.find("gemm4w_kernelILi", pos)
+        if i < 0:
+            break
+        j = src.index("\n", i)
+        ls = src.rfind("\n", 0, i) + 1
+        line = src[ls:j]
+        if not (line.startswith("_Z") and ":" in line.split(";")[0]):      # the label line "name:   ; @name"
+            pos = j
+            continue
+        e = src.index("s_endpgm", j)
+        nker += 1
+        inasm = False
+        for ln in src[j:e].split("\n"):
+            if "ASMSTART" in ln:
+                inasm = True
+            elif "ASMEND" in ln:
+                inasm = False
+            elif not inasm and ("accvgpr" in ln or "scratch_" in ln or " a[" in ln):
+                bad += 1
+                print(src[i:j], ln)
+        pos = e
+    print(f"{path}: {bad} accumulator-file / scratch statements outside the hand-written ones ({nker} kernels checked)")
+    return 1 if bad else 0
+
+
 def main():
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--check":
+        sys.exit(check(sys.argv[2]))
     nk = 12                                   # model run: steady tiles 0 .. nk - 4, then three tail tiles
     ev, marks = run_events(nk)
     waits = annotate(ev)
@@ -139,7 +183,16 @@ def main():
     assert text[0] == text[2] and text[1] == text[3], "the first tiles already are the steady state"
     path = os.path.join(HERE, "gemm4w_lab.hip")
     src = open(path).read()
+    # the two K-tiles behind an epilogue: their LDS writes need loads that are OLDER than the epilogue's 32 stores -- counted
+    # with the stores in the queue (vector-memory operations of a wave complete in order on gfx9 / CDNA), so that they do not
+    # wait for the store burst to drain
+    ev2, marks2 = run_events(20, stores_after=7)
+    waits2 = annotate(ev2)
+    text2 = {kt: emit_range(ev2, waits2, marks2[kt], marks2[kt + 1]) for kt in range(20)}
+    assert text2[2] == text[2] and text2[7] == text[3] and text2[10] == text[2] and text2[11] == text[3], "steady again from the third K-tile on"
+    assert text2[8] != text[2]
     blocks = {"PROLOGUE": emit_range(ev, waits, 0, marks[0]), "STEADY0": text[2], "STEADY1": text[3], "STEADY0B": text[2],
+              "POST0": text2[8], "POST1": text2[9],
               "TAIL3": text[nk - 3], "TAIL2": text[nk - 2], "TAIL1": text[nk - 1]}
     assert (nk - 3) & 1 == 1 and (nk - 4) & 1 == 0
     for tag, body in blocks.items():
