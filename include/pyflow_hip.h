@@ -93,7 +93,9 @@ long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
  * the narrow-N conv kernel (3x3x3 convs with <= 8 output channels: the decoder's conv_out); -4 / 4 = never / again
  * split the tail tiles of gemm8p problems that bring a workspace (also: the whole-launch K split of 32 .. 128-tile problems);
  * -5 / 5 = never / again the LDS-halo direct conv; -6 / 6 = halo conv only for N = 128 / also for wider layers; -7 / 7 = the
- * upsamplers' output maps stay with the implicit GEMM / take the halo kernel; 400 + c (c = 0..199) = measurement hook: the
+ * upsamplers' output maps stay with the implicit GEMM / take the halo kernel; 9 / -9 = desynchronised start of the persistent
+ * kernel's workgroups on / off (workgroups with a tile less than the busiest of their XCD wait out a fraction of a tile time, so
+ * that the chip's 256 epilogues do not store in one burst; timing only, same bits; off by default); 400 + c (c = 0..199) = measurement hook: the
  * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0).  Default 0. */
 int pf_gemm_set_policy(int force);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =

@@ -267,6 +267,7 @@ int pf_gemm256_launch(const pfgemm::Args& a, int bn, bool conv, hipStream_t stre
 int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream, void* ws, long long ws_bytes);   // gemm8p.hip: persistent 256 x 256 tiles
 void pf_gemm8p_set_tail_split(bool on);
 void pf_gemm8p_set_tail_overhead(int k_tiles);
+void pf_gemm8p_set_stagger(int cycles);
 long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
@@ -312,14 +313,16 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 5 || force == -5) { g_halo_enabled = force > 0; return 0; }
     if (force == 6 || force == -6) { g_halo_wide = force > 0; return 0; }
     if (force == 7 || force == -7) { g_halo_maps = force > 0; return 0; }
+    if (force == 9 || force == -9) { pf_gemm8p_set_stagger(force > 0 ? 290 : 0); return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-7, 8, -8, 128, 192 or 256");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256 or 400 + c");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
     pf_gemm8p_set_tail_split(true);
     pf_gemm8p_set_tail_overhead(4);          // the measurement hook (400 + c) does not outlive a reset to automatic
+    pf_gemm8p_set_stagger(0);
     return 0;
 }
 // Scratch that pays for this problem (pf_gemm_desc.workspace): 0 = none is used.  Large problems on the persistent 256 x 256

@@ -121,6 +121,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         tail_tile = cs + tp.n_full * nslot + slot; tail_k1 = nk;
     }
     const bool tail_parks = tp.sp > 1;              // the tail segment ends with raw sums in scratch, not with an epilogue
+    // DESYNCHRONISED START (round 4, off by default: pf_gemm_set_policy(9)).  All workgroups walk equally long tiles in lockstep,
+    // so their epilogues -- 128 KiB of C each -- leave the chip in one 32-MB burst per round (~12 000 cycles per tile, 14 % of a
+    // K = 1920 tile: lab/gemm4w_lab.hip measured it on a second GEMM structure).  A workgroup whose XCD chunk gives it one tile
+    // less than the busiest ones (no tail split: slot >= r) can wait out a fraction of a tile time for free; its epilogues then
+    // fall into the others' main loops.  Timing only: tiles, order and arithmetic are unchanged.
+    if (!CONV && p.stagger > 0 && tp.sp == 1 && tp.r > 0 && slot >= tp.r) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)((slot - tp.r) & 7) * (unsigned)p.stagger * (unsigned)nk;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     const int n_full = tp.n_full;
     const int n_my = n_full + (tail_tile >= 0 ? 1 : 0);
     if (n_my == 0) return;
@@ -702,6 +712,7 @@ __global__ __launch_bounds__(256) void gemm8p_tail_kernel(const Args p) {
 int g_num_cu = 0;
 bool g_tail_split = true;                  // pf_gemm_set_policy(-4) / (4): never / again split the tail tiles along K
 int g_tail_ov = 4;                         // fixed cost of a split in K-tile periods (tail_plan; pf_gemm_set_policy(400 + ov))
+int g_stagger = 0;                         // pf_gemm_set_policy(9) / (-9): desynchronised start on (290 cycles per K-tile and 1/8 step) / off
 
 template <bool CONV, int EPI>
 int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
@@ -723,6 +734,7 @@ int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
     a.part = nullptr;
     a.ksplit = grid;
     a.tail_ov = g_tail_ov;
+    a.stagger = g_stagger;
     int rmax = 0;
     if (!CONV && g_tail_split && ws && (grid & 7) == 0 && ws_bytes >= (long long)grid * (256 << 10)) {
         const int nk = a.K / BK, nslot = grid >> 3;
@@ -764,6 +776,7 @@ int pf_gemm8p_mid_split(int tiles, int nk) {
 
 void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }
 void pf_gemm8p_set_tail_overhead(int k_tiles) { g_tail_ov = k_tiles; }
+void pf_gemm8p_set_stagger(int cycles) { g_stagger = cycles; }
 
 // Scratch (bytes) with which pf_gemm8p_launch may split the tail tiles of a problem along K (one slot per workgroup).
 long long pf_gemm8p_workspace_bytes() { return 256ll * (256 << 10); }
