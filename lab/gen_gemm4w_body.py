@@ -20,8 +20,15 @@ vector-memory and LDS queues and takes, for every statement that needs an earlie
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FRAG_ORDER = ["W0", "A0", "A1", "A2", "A3", "W1", "W2", "W3"]
-WRITES_PER_KSTEP = [6, 5, 5, 0]
+NB = 4                                      # N-blocks of 32 columns per wave: 4 = 256-wide tile, 3 = 192-wide (set by main())
+
+
+def frag_order():
+    return ["W0", "A0", "A1", "A2", "A3"] + [f"W{j}" for j in range(1, NB)]
+
+
+def writes_per_kstep():
+    return [6, 5, 5, 0] if NB == 4 else [5, 5, 4, 0]
 
 
 def tile_events(kt, nk):
@@ -33,29 +40,34 @@ def tile_events(kt, nk):
     nl = 0                                   # loads of tile kt + 3 issued so far
     do_w = kt + 1 < nk
     do_l = kt + 3 < nk
+    FRAG_ORDER, WRITES_PER_KSTEP, NMEM = frag_order(), writes_per_kstep(), 8 + 2 * NB
     for ks in range(4):
         ev.append(("need_frags", kt, ks))
         slot = 0
-        for jn in range(4):
+        for jn in range(NB):
             for im in range(4):
                 ev.append(("mfma", jn, im, ks & 1))
-                if slot < 8:
+                if slot < len(FRAG_ORDER):
                     op, blk = FRAG_ORDER[slot][0], int(FRAG_ORDER[slot][1])
                     if ks < 3:
                         ev.append(("rd", op, b, ks + 1, blk, (ks + 1) & 1, kt, ks + 1))
                     elif kt + 1 < nk:
                         ev.append(("rd", op, b ^ 1, 0, blk, 0, kt + 1, 0))
                 else:
+                    wrote = False
                     if do_w and nw < sum(WRITES_PER_KSTEP[:ks + 1]):
                         ev.append(("wr", kt + 1, nw))
                         nw += 1
-                    elif do_l and nl < nw:
+                        wrote = True
+                    # 192-wide tile: 48 MFMAs for 28 reads + 14 writes + 14 loads -- a write slot also carries the load
+                    # into the registers it has just drained
+                    if do_l and nl < nw and nl < NMEM and (NB == 3 or not wrote):
                         ev.append(("ld", kt + 3, nl))
                         nl += 1
-                    if ks == 2 and slot == 15 and kt + 1 < nk:
+                    if ks == 2 and slot == 4 * NB - 1 and kt + 1 < nk:
                         ev.append(("barrier", kt))
                 slot += 1
-    assert (not do_w or nw == 16) and (not do_l or nl == 16), (kt, nw, nl)
+    assert (not do_w or nw == NMEM) and (not do_l or nl == NMEM), (kt, nw, nl)
     return ev
 
 
@@ -63,23 +75,23 @@ def run_events(nk, stores_after=None):
     """stores_after = stream K-tile index after which an epilogue issues its 32 global stores (they sit in the same in-order
     vector-memory queue as the loads)"""
     ev = []
+    NMEM = 8 + 2 * NB
     for t in (0, 1):                          # prologue: tiles 0 and 1 requested, tile 0 written, tile 2 requested into the set
-        for i in range(16):                   # tile 0 left, tile 0's first fragments read
+        for i in range(NMEM):                 # tile 0 left, tile 0's first fragments read
             ev.append(("ld", t, i))
-    for i in range(16):
+    for i in range(NMEM):
         ev.append(("wr", 0, i))
-    for i in range(16):
+    for i in range(NMEM):
         ev.append(("ld", 2, i))
     ev.append(("barrier", -1))
-    for slot in range(8):
-        op, blk = FRAG_ORDER[slot][0], int(FRAG_ORDER[slot][1])
-        ev.append(("rd", op, 0, 0, blk, 0, 0, 0))
+    for f in frag_order():
+        ev.append(("rd", f[0], 0, 0, int(f[1]), 0, 0, 0))
     marks = {}
     for kt in range(nk):
         marks[kt] = len(ev)
         ev += tile_events(kt, nk)
         if stores_after is not None and kt == stores_after:
-            ev += [("st", kt, i) for i in range(32)]
+            ev += [("st", kt, i) for i in range(8 * NB)]
     marks[nk] = len(ev)
     return ev, marks
 
@@ -171,8 +183,14 @@ def check(path):
 
 def main():
     import sys
+    global NB
     if len(sys.argv) > 2 and sys.argv[1] == "--check":
         sys.exit(check(sys.argv[2]))
+    for NB in (4, 3):
+        generate("" if NB == 4 else "_N3")
+
+
+def generate(suffix):
     nk = 12                                   # model run: steady tiles 0 .. nk - 4, then three tail tiles
     ev, marks = run_events(nk)
     waits = annotate(ev)
@@ -196,6 +214,7 @@ def main():
               "TAIL3": text[nk - 3], "TAIL2": text[nk - 2], "TAIL1": text[nk - 1]}
     assert (nk - 3) & 1 == 1 and (nk - 4) & 1 == 0
     for tag, body in blocks.items():
+        tag += suffix
         a = src.index(f"// GENERATED {tag} BEGIN")
         b = src.index(f"// GENERATED {tag} END")
         src = src[:a] + f"// GENERATED {tag} BEGIN (lab/gen_gemm4w_body.py)\n" + body + "        " + src[b:]
