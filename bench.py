@@ -334,7 +334,11 @@ def main():
             elif args.comm in ("auto", "native"):
                 # ranks sharing a GPU (test boxes): RCCL refuses duplicate devices, its init is not even attempted
                 comm_errors.append("pf_comm: not attempted (backend gloo: the ranks share GPUs, RCCL needs one GPU per rank)")
-            if comm is None:          # torch.distributed: the agreed fallback of --comm auto / native, the choice of --comm torch
+            if comm is None and args.comm == "native":
+                # an explicit request is strict: a line labelled "native" is never measured on another transport
+                raise SystemExit("[bench] --comm native: the C-ABI communicator is not available on every rank: " +
+                                 " | ".join(comm_errors) + "  (use --comm auto for the torch.distributed fallback)")
+            if comm is None:          # torch.distributed: the agreed fallback of --comm auto, the choice of --comm torch
                 comm, ok = try_comm(False)
                 if not agreed(ok):
                     comm = None

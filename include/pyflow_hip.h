@@ -98,9 +98,14 @@ long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
  * that the chip's 256 epilogues do not store in one burst; timing only, same bits; off by default); 400 + c (c = 0..199) = measurement hook: the
  * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0).  Default 0. */
 int pf_gemm_set_policy(int force);
-/* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K): 0 = gemm_kernel (128x128), 8 =
- * gemm8p_kernel, BN > 0 = gemm256_kernel<BN> -- lets a profiler attribute launches to the kernel names rocprofv3 reports */
+/* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K) when the caller brings the scratch
+ * pf_gemm_workspace_bytes asks for and no QK epilogue: 0 = gemm_kernel (128x128), 8 = gemm8p_kernel, BN > 0 =
+ * gemm256_kernel<BN> */
 int pf_gemm_which(int M, int batch, int N, int K);
+/* ... and for ONE descriptor exactly as pf_gemm_bf16 decides (a mid-size problem takes the persistent kernel only with
+ * enough scratch and without a QK epilogue; epilogue flavours gemm8p has no instantiation of go to the older kernels)
+ * -- lets a profiler attribute launches to the kernel names rocprofv3 reports.  -100 = invalid descriptor. */
+int pf_gemm_which_desc(const pf_gemm_desc* d);
 
 /* ------------------------------------------------------------------ CausalConv3d ----------------
  * Implicit-GEMM convolution over a channels-last, zero-padded input (replaces CausalConv3d.forward,
@@ -129,8 +134,9 @@ typedef struct {
     /* optional: GroupNorm statistics of the OUTPUT accumulated by the conv's epilogue (CausalGroupNorm of the layer that
      * reads Y: modeling_causal_conv.py:36-43), double [T][gn_C][2] = (sum, sum of squares) per output frame and channel,
      * zeroed by the caller -- the layout pf_gn_stats writes, so pf_gn_apply can follow without a pf_gn_stats pass.
-     * Honoured only where pf_conv3d_fuses_gn_stats(desc) returns 1 (the 256-row kernel, plain output map, frames of a
-     * multiple of 256 pixels); otherwise ignored and the caller runs pf_gn_stats.  NULL = none. */
+     * Honoured only where pf_conv3d_fuses_gn_stats(desc) returns 1 (plain output map; the LDS-halo direct convolution, or
+     * the 256-row implicit-GEMM kernel on frames of a multiple of 256 pixels); otherwise ignored and the caller runs
+     * pf_gn_stats.  NULL = none. */
     double* gn_stats;
     int gn_C;
 } pf_conv_desc;

@@ -416,8 +416,12 @@ static bool use_w64(const pf_attn_desc* d) {
     const int qt0 = d->q_row_begin > 0 ? d->q_row_begin / QB : 0;
     const long long grid64 = (long long)((nqt + 1) / 2 - qt0 / 2) * d->H * d->B;
     // at least one round of the chip after the KV split (4 parts from 128 workgroups up)
-    const bool enough = grid64 * w64_split(grid64, (d->L + KB - 1) / KB) >= 512;
-    return d->workspace_bytes >= pf_attention_workspace_bytes(d->B, d->H, d->L) && enough && (d->ldo % 8) == 0 &&
+    const int sp = w64_split(grid64, (d->L + KB - 1) / KB);
+    const bool enough = grid64 * sp >= 512;
+    // scratch THIS launch touches: the flag words, and the KV-split region only when the launch splits
+    // (pf_attention_workspace_bytes is the bound that serves every q_row_begin of the shape)
+    const long long need = w64_flag_bytes(d->B, d->H, d->L) + (sp > 1 ? (long long)SPLIT_UNITS * 4 * (PART_BYTES + 16) : 0);
+    return d->workspace_bytes >= need && enough && (d->ldo % 8) == 0 &&
            (d->strideO % 8) == 0 && ((uintptr_t)d->O % 16) == 0 && ((uintptr_t)d->workspace % 4) == 0;
 }
 

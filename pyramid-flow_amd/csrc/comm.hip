@@ -90,6 +90,17 @@ struct pf_comm {
         if (rc_ != 0) return rccl_fail(where, rc_); \
     } while (0)
 
+// A call between GroupStart and GroupEnd that fails must not leave the communicator inside an open group (the next
+// collective would be queued into it and hang instead of reporting): close the group, then report the FIRST error.
+#define PF_RCCL_IN_GROUP(call, where)             \
+    do {                                          \
+        const int rc_ = (call);                   \
+        if (rc_ != 0) {                           \
+            g_api.GroupEnd();                     \
+            return rccl_fail(where, rc_);         \
+        }                                         \
+    } while (0)
+
 static int order_after(pf_comm* c, hipStream_t compute) {
     if (hipEventRecord(c->ev_in, compute) != hipSuccess) return pf_set_err("pf_comm: hipEventRecord failed");
     if (hipStreamWaitEvent(c->stream, c->ev_in, 0) != hipSuccess) return pf_set_err("pf_comm: hipStreamWaitEvent failed");
@@ -154,9 +165,9 @@ extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* se
     PF_RCCL(g_api.GroupStart(), "pf_all_to_all_v");
     for (int p = 0; p < c->world; ++p) {
         if (send_bytes[p] > 0)
-            PF_RCCL(g_api.Send((const char*)send + send_offs[p], (size_t)send_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
+            PF_RCCL_IN_GROUP(g_api.Send((const char*)send + send_offs[p], (size_t)send_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
         if (recv_bytes[p] > 0)
-            PF_RCCL(g_api.Recv((char*)recv + recv_offs[p], (size_t)recv_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
+            PF_RCCL_IN_GROUP(g_api.Recv((char*)recv + recv_offs[p], (size_t)recv_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
     }
     PF_RCCL(g_api.GroupEnd(), "pf_all_to_all_v");
     return 0;
@@ -168,9 +179,9 @@ extern "C" int pf_halo_send_recv(pf_comm* c, const void* send, void* recv, long 
     if (order_after(c, compute)) return -1;
     PF_RCCL(g_api.GroupStart(), "pf_halo_send_recv");
     if (c->rank + 1 < c->world && bytes > 0)
-        PF_RCCL(g_api.Send(send, (size_t)bytes, RCCL_UINT8, c->rank + 1, c->comm, c->stream), "pf_halo_send_recv");
+        PF_RCCL_IN_GROUP(g_api.Send(send, (size_t)bytes, RCCL_UINT8, c->rank + 1, c->comm, c->stream), "pf_halo_send_recv");
     if (c->rank > 0 && bytes > 0)
-        PF_RCCL(g_api.Recv(recv, (size_t)bytes, RCCL_UINT8, c->rank - 1, c->comm, c->stream), "pf_halo_send_recv");
+        PF_RCCL_IN_GROUP(g_api.Recv(recv, (size_t)bytes, RCCL_UINT8, c->rank - 1, c->comm, c->stream), "pf_halo_send_recv");
     PF_RCCL(g_api.GroupEnd(), "pf_halo_send_recv");
     return 0;
 }
@@ -183,9 +194,9 @@ extern "C" int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const l
     PF_RCCL(g_api.GroupStart(), "pf_all_gather_v");
     for (int p = 0; p < c->world; ++p) {
         if (bytes[c->rank] > 0)
-            PF_RCCL(g_api.Send(send, (size_t)bytes[c->rank], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
+            PF_RCCL_IN_GROUP(g_api.Send(send, (size_t)bytes[c->rank], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
         if (bytes[p] > 0)
-            PF_RCCL(g_api.Recv((char*)recv + offs[p], (size_t)bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
+            PF_RCCL_IN_GROUP(g_api.Recv((char*)recv + offs[p], (size_t)bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
     }
     PF_RCCL(g_api.GroupEnd(), "pf_all_gather_v");
     return 0;

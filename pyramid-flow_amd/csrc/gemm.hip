@@ -268,6 +268,7 @@ int pf_gemm8p_launch(const pfgemm::Args& a, bool conv, hipStream_t stream, void*
 void pf_gemm8p_set_tail_split(bool on);
 void pf_gemm8p_set_tail_overhead(int k_tiles);
 void pf_gemm8p_set_stagger(int cycles);
+void pf_gemm8p_set_epi_mode(int mode);
 long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
@@ -315,14 +316,16 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 7 || force == -7) { g_halo_maps = force > 0; return 0; }
     if (force == 9 || force == -9) { pf_gemm8p_set_stagger(force > 0 ? 290 : 0); return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
+    if (force >= 1000 && force < 1064) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // measurement hook: Args::epi_mode bits
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256 or 400 + c");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c or 1000 + m");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
     pf_gemm8p_set_tail_split(true);
     pf_gemm8p_set_tail_overhead(4);          // the measurement hook (400 + c) does not outlive a reset to automatic
     pf_gemm8p_set_stagger(0);
+    pf_gemm8p_set_epi_mode(3);
     return 0;
 }
 // Scratch that pays for this problem (pf_gemm_desc.workspace): 0 = none is used.  Large problems on the persistent 256 x 256
@@ -337,14 +340,32 @@ extern "C" long long pf_gemm_workspace_bytes(int M, int batch, int N, int K) {
     ks = ks < nk / 4 ? ks : nk / 4;
     return ks > 1 ? (long long)ks * batch * M * N * 4 : 0;
 }
-extern "C" int pf_gemm_which(int M, int batch, int N, int K) {   // 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>
+// The kernel a problem of this size takes WHEN the caller brings the scratch pf_gemm_workspace_bytes asks for and no QK
+// epilogue: 0 = 128x128 kernel, 8 = gemm8p_kernel, BN = gemm256_kernel<BN>.  (pf_gemm_which_desc: the decision for one
+// descriptor as pf_gemm_bf16 takes it.)
+extern "C" int pf_gemm_which(int M, int batch, int N, int K) {
     if (use_gemm8p(M, batch, N, K)) return 8;
     return pf_gemm256_pick((long long)M * batch, M, batch, N, gemm256_force());
+}
+// pf_gemm_bf16's routing, shared with pf_gemm_which_desc: 8 = the persistent kernel (a whole-round launch, or a mid-size one
+// that brings enough scratch to split K and has no QK epilogue: the split's second launch applies none), else the 256-row
+// kernel's tile width, else 0 = the 128 x 128 kernel
+static int gemm_route(const pf_gemm_desc* d, const Args& a) {
+    const bool qk = d->qk_d > 0;
+    const int kind8 = use_gemm8p_kind(d->M, d->batch, d->N, d->K);
+    const bool ws8 = !qk && d->workspace && d->workspace_bytes >= pf_gemm8p_workspace_bytes();
+    if ((kind8 == 1 || (kind8 == 2 && ws8)) && pf_gemm8p_supports(a, false)) return 8;
+    return pf_gemm256_pick((long long)d->M * d->batch, d->M, d->batch, d->N, gemm256_force());
+}
+extern "C" int pf_gemm_which_desc(const pf_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->batch <= 0 || d->N <= 0 || d->K <= 0) return -100;
+    Args a{};
+    a.N = d->N; a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
+    return gemm_route(d, a);
 }
 extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
     if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
-    const int bn256 = pf_gemm256_pick((long long)d->M * d->batch, d->M, d->batch, d->N, gemm256_force());
     if (d->K % BK != 0 || d->K <= 0) return set_err("pf_gemm_bf16: K must be a positive multiple of 64");
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8)) return set_err("pf_gemm_bf16: leading dims must be multiples of 8");
     if ((d->flags & PF_GEMM_GATE_RES) && !d->res) return set_err("pf_gemm_bf16: GATE_RES needs res");
@@ -377,9 +398,9 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
                                d->qk_q_scale, 64, stream);
     };
     // (a mid-size problem takes the persistent kernel only with its scratch: without it the older kernels fill the chip better)
-    const int kind8 = use_gemm8p_kind(d->M, d->batch, d->N, d->K);
-    const bool ws8 = !qk && d->workspace && d->workspace_bytes >= pf_gemm8p_workspace_bytes();
-    const bool g8 = (kind8 == 1 || (kind8 == 2 && ws8)) && pf_gemm8p_supports(a, false);
+    const int route = gemm_route(d, a);
+    const bool g8 = route == 8;
+    const int bn256 = g8 ? 0 : route;
     if (!g8 && !bn256 && d->N % BN != 0)
         return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");
     if (g8) {
@@ -442,7 +463,9 @@ static int conv_route(const pf_conv_desc* d, const Args& a) {
     if (g_narrow_enabled && pf_conv_narrow_supports(d)) return -1;
     if (g_halo_enabled && gemm256_force() == 0 && pf_conv_halo_supports(d, g_halo_wide) &&
         (g_halo_maps || (d->st == 1 && d->sh == 1 && d->sw == 1))) return -2;
-    if (use_gemm8p(a.M, 1, a.N, a.K) && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) return 8;
+    // (kind 2 = a mid-size launch that pays only with a K split through scratch: a conv never splits -- it stays with the
+    //  256-row kernels, which also fuse the GroupNorm statistics)
+    if (use_gemm8p_kind(a.M, 1, a.N, a.K) == 1 && a.n_valid % 8 == 0 && pf_gemm8p_supports(a, true)) return 8;
     return pf_gemm256_pick(a.M, a.M, 1, a.N, gemm256_force());
 }
 // GroupNorm statistics in the conv epilogue: only the 256-row ping-pong kernel at BN = 128 / 256 accumulates them, for a

@@ -387,7 +387,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         f32x4_t gate4[2][2];
         f32x4_t rb0, rb1;                                       // residual flavour: bias of the current column half
         const bool more_tiles = seq + 1 < n_my;
-        if (FOLD_BIAS && more_tiles) load_bias(seq + 1);       // consumed after the stores are issued (acc_from_bias)
+        // the next tile's bias: consumed after the stores are issued (acc_from_bias).  Requested AFTER the epilogue's first
+        // drain (epi_mode bit 1) so that the drain does not wait for four fresh global loads
+        const bool bias_late = (p.epi_mode & 2) != 0;
+        if (FOLD_BIAS && more_tiles && !bias_late) load_bias(seq + 1);
         auto load_col_params = [&](int hsel) {
             const int n_raw = wave_n0 + 32 * hsel + 8 * fq;
             ncol_ok[hsel] = n_raw < p.n_valid;
@@ -469,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     // drains the DMA queue (see the main loop) and, for the residual / QK flavours, this batch's pieces
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PF_FENCE();
+                    if (hsel == 0 && f0 == 0 && FOLD_BIAS && more_tiles && bias_late) load_bias(seq + 1);
                 }
 #pragma unroll
                 for (int fi = 0; fi < FB; ++fi) {
@@ -619,7 +623,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         // phase 3: no fragment reads (B sub 0 is still resident) | (A1, B0)
         end_of_load_slot(g + 3);
         mfma_quadrant(1, 0);
-        if (++c_kt == c_end) {
+        // TILE BOUNDARY.  Group 1 runs one barrier behind group 0: with both epilogues in front of the loop's last barrier,
+        // group 0's epilogue runs beside group 1's (short) load slot and group 1's beside group 0's next load slot -- one
+        // after the other, the matrix pipe idle through both.  epi_mode bit 0: group 0 takes the barrier FIRST, so that its
+        // epilogue falls into the same barrier interval as group 1's MFMA slot + epilogue (register work, drains and store
+        // issue of the two groups overlap; nothing else moves: the epilogue touches no LDS and issues no DMA).
+        const bool tile_done = ++c_kt == c_end;
+        const bool late = tile_done && wm == 0 && (p.epi_mode & 1);
+        if (late) PF_BAR();
+        if (tile_done) {
             // every DMA issued so far has had >= one MFMA slot; draining here makes the waits of the next four load
             // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
             // epilogue out of the counted waits
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             c_kt = seg_begin(c_tile);
             c_end = seg_end(c_tile);
         }
-        PF_BAR();
+        if (!late) PF_BAR();
     }
     if (wm == 0) PF_BAR();                 // matches group 1's extra barrier
 }
@@ -713,6 +725,7 @@ int g_num_cu = 0;
 bool g_tail_split = true;                  // pf_gemm_set_policy(-4) / (4): never / again split the tail tiles along K
 int g_tail_ov = 4;                         // fixed cost of a split in K-tile periods (tail_plan; pf_gemm_set_policy(400 + ov))
 int g_stagger = 0;                         // pf_gemm_set_policy(9) / (-9): desynchronised start on (290 cycles per K-tile and 1/8 step) / off
+int g_epi_mode = 3;                        // Args::epi_mode (pf_gemm_set_policy(1000 + m): measurement hook)
 
 template <bool CONV, int EPI>
 int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
@@ -735,6 +748,7 @@ int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
     a.ksplit = grid;
     a.tail_ov = g_tail_ov;
     a.stagger = g_stagger;
+    a.epi_mode = g_epi_mode;
     int rmax = 0;
     if (!CONV && g_tail_split && ws && (grid & 7) == 0 && ws_bytes >= (long long)grid * (256 << 10)) {
         const int nk = a.K / BK, nslot = grid >> 3;
@@ -777,6 +791,7 @@ int pf_gemm8p_mid_split(int tiles, int nk) {
 void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }
 void pf_gemm8p_set_tail_overhead(int k_tiles) { g_tail_ov = k_tiles; }
 void pf_gemm8p_set_stagger(int cycles) { g_stagger = cycles; }
+void pf_gemm8p_set_epi_mode(int mode) { g_epi_mode = mode; }
 
 // Scratch (bytes) with which pf_gemm8p_launch may split the tail tiles of a problem along K (one slot per workgroup).
 long long pf_gemm8p_workspace_bytes() { return 256ll * (256 << 10); }

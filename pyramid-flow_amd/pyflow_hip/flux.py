@@ -229,7 +229,9 @@ class FluxEngine(DeviceModuleAPI):
                 p_.__dict__.pop("_launch_list", None)
         return t
 
-    def make_plan(self, clip_shapes, enc_mask):
+    def make_plan(self, clip_shapes, enc_mask, cfg_pair=False):
+        """cfg_pair: the two rows of `enc_mask` are the [negative | positive] guidance pair of ONE sample (pipeline.py:747);
+        only the guidance-parallel engine (flux_cfg.py) treats that differently from a genuine batch of 2"""
         plan = SequencePlan(clip_shapes, enc_mask, self.w.rope_axes, self.dev)
         if self.w.mmdit:
             plan.pos = self._pos_rows(clip_shapes)
@@ -255,8 +257,8 @@ class FluxEngine(DeviceModuleAPI):
             rows.append(pe.reshape(1, h2 * w2, -1).expand(t, -1, -1).reshape(t * h2 * w2, -1))
         return torch.cat(rows, 0).to(self.dev, torch.bfloat16).contiguous()
 
-    def encode_context(self, enc):
-        """context_embedder (flux:401): enc [B, Lt, C] -> cached bf16 [B, Lt, d]."""
+    def encode_context(self, enc, cfg_pair=False):
+        """context_embedder (flux:401): enc [B, Lt, C] -> cached bf16 [B, Lt, d].  cfg_pair: see make_plan."""
         w = self.w
         B, Lt, Cc = enc.shape
         x = torch.zeros(B * Lt, w.ctx_k, dtype=torch.bfloat16, device=self.dev)

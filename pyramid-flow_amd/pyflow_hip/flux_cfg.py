@@ -36,15 +36,21 @@ class FluxEngineCFG(FluxEngine):
             self._row_cache[id(t)] = ent
         return ent[2]
 
-    def make_plan(self, clip_shapes, enc_mask):
-        if enc_mask.shape[0] != 2:
+    def make_plan(self, clip_shapes, enc_mask, cfg_pair=False):
+        # the caller SAYS that the two rows are one sample's guidance pair (the pipeline does, under classifier-free
+        # guidance); a genuine batch of 2 handed to the engine-level API takes the replicated base path on every rank
+        if not cfg_pair:
             return super().make_plan(clip_shapes, enc_mask)
+        assert enc_mask.shape[0] == 2, "a guidance pair has exactly two prompt rows"
         plan = super().make_plan(clip_shapes, enc_mask[self.comm.rank:self.comm.rank + 1])
         plan.cfg_pair = True
         return plan
 
-    def encode_context(self, enc):
-        return super().encode_context(enc if enc.shape[0] != 2 else enc[self.comm.rank:self.comm.rank + 1])
+    def encode_context(self, enc, cfg_pair=False):
+        if not cfg_pair:
+            return super().encode_context(enc)
+        assert enc.shape[0] == 2, "a guidance pair has exactly two prompt rows"
+        return super().encode_context(enc[self.comm.rank:self.comm.rank + 1])
 
     def forward_tokens(self, plan, clips, timesteps, pooled, ctx=None, shared_clips=False, debug=None):
         if not getattr(plan, "cfg_pair", False):          # no guidance pair (guidance scale 1): every rank computes the same

@@ -83,15 +83,10 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
         check(lib.pf_cmdlist_gemm(rec.h, C.byref(d), C.c_int(rec.slot)))
         return
     if PROFILER.enabled:      # attribute the launch to the kernel rocprofv3 will name
-        bn = lib.pf_gemm_which(C.c_int(M), C.c_int(batch), C.c_int(N), C.c_int(K))
+        bn = lib.pf_gemm_which_desc(C.byref(d))       # pf_gemm_bf16's own routing of THIS descriptor (scratch, QK, flavour)
         if bn == 8:       # the epilogue flavour is a template argument: same names as in a rocprofv3 kernel trace
             epi = 12 if qk is not None else (1 if (flags & GEMM_GATE_RES) else (2 if (flags & GEMM_OUT_F32) else (4 if 0 <= gelu_from < N else 0)))
-            ok = not (flags & (GEMM_ACT_QUICK_GELU | GEMM_ACT_GELU_ERF)) and \
-                (int(bool(flags & GEMM_GATE_RES)) + int(bool(flags & GEMM_OUT_F32)) + int(0 <= gelu_from < N)) <= 1
-            if not ok:    # flavour not instantiated (CLIP activations, combinations): served by the older kernels
-                bn = -1
-        name = f"gemm8p_kernel<false, {epi}>" if bn == 8 else (f"gemm256_kernel<{bn}>" if bn > 0 else (
-            "gemm_kernel(128x128)" if bn == 0 else "gemm (older kernel, flavour without a gemm8p instantiation)"))
+        name = f"gemm8p_kernel<false, {epi}>" if bn == 8 else (f"gemm256_kernel<{bn}>" if bn > 0 else "gemm_kernel(128x128)")
     else:
         name = "gemm"
     PROFILER.launch(name, 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))

@@ -176,12 +176,13 @@ class PyramidDiTForVideoGeneration:
 
     # ---- plan cache
     def _plan(self, shapes, mask):
-        key = (tuple(shapes), mask.cpu().numpy().tobytes())
+        pair = bool(self.do_classifier_free_guidance)        # the rows of `mask` are one sample's [negative | positive] pair
+        key = (tuple(shapes), mask.cpu().numpy().tobytes(), pair)
         p = self._plans.get(key)
         if p is None:
             if len(self._plans) > 8:
                 self._plans.clear()
-            p = self.dit.make_plan(shapes, mask)
+            p = self.dit.make_plan(shapes, mask, cfg_pair=pair)
             self._plans[key] = p
         return p
 
@@ -247,7 +248,7 @@ class PyramidDiTForVideoGeneration:
                 x = xs[b]
                 emb, prompt_mask, pooled = ctxs[b]
                 if emb is not None:
-                    self.dit.encode_context(emb)
+                    self.dit.encode_context(emb, cfg_pair=bool(self.do_classifier_free_guidance))
                 self.scheduler.set_timesteps(num_inference_steps[i_s], i_s, device=None)
                 clips = pasts[b][i_s] + [x[None]]
                 shapes = [tuple(c.shape[2:]) for c in clips]
@@ -318,7 +319,7 @@ class PyramidDiTForVideoGeneration:
             ctxs += [ctx] * n_img                # repeat_interleave order of the text encoders' num_images_per_prompt
         nb *= n_img
         if nb == 1:                              # one sample: its context is encoded once for the whole run
-            self.dit.encode_context(ctxs[0][0])
+            self.dit.encode_context(ctxs[0][0], cfg_pair=bool(self.do_classifier_free_guidance))
             ctxs = [(None, ctxs[0][1], ctxs[0][2])]
         C = self.dit.w.out_cols // 4
         latents = self.prepare_latents(nb, C, temp, height, width, pe.dtype, self._device, generator)
@@ -448,7 +449,7 @@ class PyramidDiTForVideoGeneration:
             pp = torch.cat([npool, pp], dim=0)
             pm = torch.cat([nm, pm], dim=0)
         self._round = (self.model_dtype == "bf16") and pe.dtype == torch.bfloat16
-        self.dit.encode_context(pe)
+        self.dit.encode_context(pe, cfg_pair=bool(self.do_classifier_free_guidance))
         C = self.dit.w.out_cols // 4
         latents = self.prepare_latents(1, C, temp, height, width, pe.dtype, self._device, generator)
         x = latents[0].to(self._device, torch.float32).contiguous()

@@ -46,6 +46,11 @@ def main():
     plan = eng.make_plan(shapes, mask)
     eng.encode_context(enc)
     v = eng.forward_tokens(plan, clips, t, pooled).clone()
+    # the same forward with the rank's small image GEMMs NOT split along K (FluxEngineSP.split_small = False): the summation
+    # order of the single-rank engine -> the tight bound below; the default (split) is a perf choice with a measured error
+    eng.split_small = False
+    v_ns = eng.forward_tokens(plan, clips, t, pooled).clone()
+    eng.split_small = True
     torch.cuda.synchronize()
     ok = True
     if rank == 0:
@@ -53,6 +58,7 @@ def main():
         ref_eng.encode_context(enc)
         ref = ref_eng.forward_tokens(plan, clips, t, pooled).clone()
         err = rel_l2(v.cpu(), ref.cpu())
+        err_ns = rel_l2(v_ns.cpu(), ref.cpu())
         # ... and against the CPU oracle (the reference's arithmetic), not only against the single-rank HIP engine
         if variant == "mmdit":
             from oracle.mmdit_oracle import mmdit_forward as oracle_forward
@@ -65,9 +71,9 @@ def main():
         x = x.permute(0, 1, 2, 4, 3, 5, 6).reshape(2, tcur, hcur, wcur, Cc).permute(0, 4, 1, 2, 3)
         err_oracle = rel_l2(x, o_ref)
         # (vs the single-rank engine: two bf16 evaluations whose small GEMMs split K differently since round 4)
-        ok = err < 5e-3 and err_oracle < 2e-2
+        ok = err < 5e-3 and err_ns < 2e-3 and err_oracle < 2e-2
         with open(out_path, "w") as f:
-            f.write(f"vs single-rank HIP {err:.3e}, vs oracle {err_oracle:.3e} {int(ok)} world={world} heads={heads} "
+            f.write(f"vs single-rank HIP {err:.3e} (small GEMMs unsplit: {err_ns:.3e}), vs oracle {err_oracle:.3e} {int(ok)} world={world} heads={heads} "
                     f"lay_rows={eng.layout(plan).rows} lay_heads={eng.layout(plan).heads}\n")
     # all ranks must hold the same replicated result
     gathered = [torch.empty_like(v.cpu()) for _ in range(world)]

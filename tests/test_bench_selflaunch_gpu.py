@@ -35,14 +35,21 @@ def test_self_launch_default_two_ranks_is_guidance_parallel():
 
 
 def test_self_launch_sequence_parallel_two_ranks_and_native_communicator_dry_run():
-    """--parallelism sp: the Ulysses engine on two ranks.  --comm native on a box whose ranks share ONE GPU cannot have the
-    C-ABI RCCL communicator (duplicate device): every rank takes the agreed torch.distributed fallback and the line still
-    comes out complete, naming the communicator that ran and why the requested one did not."""
-    r = _run(["--parallelism", "sp", "--comm", "native"])
+    """--parallelism sp: the Ulysses engine on two ranks.  On a box whose ranks share ONE GPU the C-ABI RCCL communicator
+    cannot exist (duplicate device): under --comm auto every rank takes the agreed torch.distributed fallback and the line
+    still comes out complete, naming the communicator that ran and why the preferred one did not; an EXPLICIT --comm native
+    is strict (round 5): no line labelled native is ever measured on another transport -- the run fails and says why."""
+    r = _run(["--parallelism", "sp", "--comm", "auto"])
     assert r["n_gpus"] == 2 and r["config"]["parallelism"].startswith("sp2") and r["value"] > 0
     assert r["communicator"].startswith("torch.distributed") and r["rccl_ranks"] == 0
     assert any("pf_comm" in e for e in r["communicator_fallback_reason"])
     assert r["phases"]["sampling_s"] > 0
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "smoke_128p_17f",
+                        "--tiny-model", "--no-cpu-baseline", "--parallelism", "sp", "--comm", "native"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode != 0 and "--comm native" in p.stderr.decode()
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.strip().startswith("{")]
 
 
 def test_self_launch_replicas_two_ranks():

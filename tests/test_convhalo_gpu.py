@@ -150,3 +150,23 @@ def test_halo_conv_upsampler_output_maps_equal_the_implicit_gemm(kind, Ci, Cg, T
     assert rel_l2(outs[True].float().cpu(), outs[False].float().cpu()) < 3e-3 and d <= 2 ** -5 * outs[False].float().abs().max().item()
     # exactly the same set of elements was written (borders, cache slots, a dropped first frame stay zero in both)
     assert torch.equal(outs[True] != 0, outs[False] != 0)
+    # ... and DIRECTLY against torch's fp32 conv3d of the same bf16 operands followed by the reference's rearranges
+    # (filters in the reference's channel order: 'b (c p1 p2) t h w -> b c t (h p1) (w p2)' modeling_resnet.py:616,
+    # 'b (c p) t h w -> b c (t p) h w' + the is_init_image first-frame drop :726-729); one op: rel-L2 <= 5e-3
+    xin = x.float().permute(3, 0, 1, 2)[None].cuda()                             # [1, Ci, T + 2, H, W], frames 0, 1 = cache slots
+    y = F.conv3d(F.pad(xin, (1, 1, 1, 1, 0, 0)), w.to(torch.bfloat16).float().cuda(), b.cuda())        # [1, co, T, H, W]
+    if kind == "spatial":
+        y = y.view(1, Cg, 2, 2, T, H, W).permute(0, 1, 4, 5, 2, 6, 3).reshape(1, Cg, T, 2 * H, 2 * W)
+        To, Ho, Wo = T, 2 * H, 2 * W
+    else:
+        y = y.view(1, Cg, 2, T, H, W).permute(0, 1, 3, 2, 4, 5).reshape(1, Cg, 2 * T, H, W)
+        To, Ho, Wo = 2 * T, H, W
+    ref = y[0].permute(1, 2, 3, 0).cpu()                                         # [To, Ho, Wo, Cg]
+    got = outs[True].view(To + 2, Ho + 2, Wo + 2, -1)[2:, 1:-1, 1:-1, :Cg].float().cpu()
+    if kind == "temporal_first":            # t_shift = -1: reference frame 0 is dropped, frame f lands in slot f - 1
+        ref = ref[1:]
+        assert got[-1].abs().max() == 0     # the last slot of the 2T-frame buffer is not written
+        got = got[:-1]
+    e_t = rel_l2(got, ref)
+    print(f"halo upsampler {kind} Ci={Ci} Cg={Cg} T={T} {H}x{W}: rel-L2 vs fp32 conv3d + rearrange {e_t:.3e}")
+    assert e_t < 5e-3

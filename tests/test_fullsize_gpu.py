@@ -70,6 +70,34 @@ def test_full_size_attention_properties_and_sampled_rows():
     s = s.masked_fill(~dm[:, None], float("-inf"))
     ref = torch.einsum("bhrl,bhld->bhrd", torch.softmax(s, -1), v).transpose(1, 2).reshape(B, len(rows), D)
     assert rel_l2(out[:, rows].float().cpu(), ref.cpu()) < 1e-2
+    # THE SHIPPED FORM (round 4 on: FluxEngine.v_rowmajor): V read token-major from its column block of the projection
+    # buffer through the hardware transpose, no V^T image -- the same sampled rows against the same fp32 restatement, the
+    # 64-rows-per-wave pair asserted, and the same bits as the V^T form
+    import ctypes as C
+    from pyflow_hip import lib
+    so = lib.load()
+    ad = lib.AttnDesc()
+    so.pf_attention_workspace_bytes.restype = C.c_longlong
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()),
+                                  int(so.pf_attention_workspace_bytes(C.c_int(B), C.c_int(H), C.c_int(L))))
+    ad.Q = qkv.data_ptr() + 2 * 2 * D
+    ad.K = qkv.data_ptr()
+    ad.V, ad.ldv, ad.strideV = qkv.data_ptr() + 2 * D, 3 * D, L * 3 * D
+    ad.O = out.data_ptr()
+    ad.ldq = ad.ldk = 3 * D
+    ad.ldo = D
+    ad.strideQ = ad.strideK = L * 3 * D
+    ad.strideO = L * D
+    ad.B, ad.H, ad.L, ad.Lp, ad.Lt, ad.q_prescaled = B, H, L, Lp, LT, 1
+    ad.workspace, ad.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert so.pf_attention_which(C.byref(ad)) == 64
+    out_tm = torch.empty_like(out)
+    ops.attention(qkv, qkv, None, out_tm, 2 * D, 0, 0, 3 * D, L * 3 * D, B, H, L, Lp, LT, plan, 0.125, q_prescaled=True,
+                  ldo=D, o_bstride=L * D, v_off=D)
+    e_tm = rel_l2(out_tm[:, rows].float().cpu(), ref.cpu())
+    print(f"L = 15488 attention, token-major V (shipped form): sampled rows vs fp32 {e_tm:.3e}")
+    assert e_tm < 1e-2
+    assert torch.equal(out_tm, out)
     # last-block form at the headline shape: q_row_begin = 11 648 = 91 x 128 (ODD 128-row tile): the 256-row workgroups
     # start at row 11 520, and must neither store nor flag the 128 rows below q_row_begin (flux.py's tail form never
     # produced their Q); rows from q_row_begin on equal the full run bit for bit
@@ -215,4 +243,68 @@ def test_full_size_forward_vs_oracle_one_block_of_each_kind():
     out = eng.forward(clips_d, enc, mask, pooled, t).cpu()
     err = rel_l2(out, ref)
     print(f"miniFLUX d=1920 H=30 L=15488 (1 double + 1 single block): forward rel-L2 vs oracle {err:.3e}")
+    assert out.shape == ref.shape and err < 2e-2
+
+
+def test_mmdit_c4_length_forward_vs_oracle():
+    """Config C4's own sequence (SD3 MMDiT, 768p image-to-video, temp 16: unit 15, stage 2 -> L = 11 888 = 128 text +
+    13 + 1 + 1 history frames + the current frame at patch size 2; CFG batch 2, d = 1536, 24 heads) through a complete
+    forward with one joint block + the context_pre_only last block against the fp32 CPU oracle (oracle/mmdit_oracle.py,
+    mmdit_modules/modeling_pyramid_mmdit.py:420-497, modeling_mmdit_block.py:624-671).  N = 1536 is 6 column tiles of the
+    persistent GEMM (other tail plans than miniFLUX's 7.5) and the attention runs 24 heads.  Tolerance: one
+    forward <= 2e-2.  The kernels this length runs are asserted: persistent 256 x 256 GEMM for every image projection, the
+    64-rows-per-wave attention pair (in place, and in the last block's row-restricted form)."""
+    import ctypes as C
+    from pyflow_hip import lib, ops, synth
+    from pyflow_hip.flux import FluxEngine
+    from oracle.mmdit_oracle import mmdit_forward
+    from util import round_sd
+    shapes = [(13, 24, 40), (1, 48, 80), (1, 96, 160), (1, 96, 160)]             # unit 15, stage 2 (SURVEY 3.4 table)
+    cfg = dict(synth.SD3_MMDIT, num_layers=2)
+    d, Hm = 1536, 24
+    sd = round_sd(synth.mmdit_state_dict(cfg, seed=22, std=0.02, lively=True))
+    sd["pos_embed.pos_embed"] = synth.mmdit_state_dict(cfg, seed=22)["pos_embed.pos_embed"]      # fp32 sincos table
+    g = torch.Generator().manual_seed(14)
+    clips = [torch.randn(2, 16, *s_, generator=g).to(torch.bfloat16).float() for s_ in shapes]
+    enc = torch.randn(2, LT, 4096, generator=g).to(torch.bfloat16).float()
+    pooled = torch.randn(2, 2048, generator=g)
+    t = torch.tensor([386.0, 386.0])
+    mask = _mask()
+    with torch.no_grad():
+        ref, inter = mmdit_forward(sd, cfg, clips, enc, mask, pooled, t, return_intermediates=True)
+    eng = FluxEngine(sd, cfg, DEV)
+    assert eng.w.mmdit and eng.w.d == d and eng.w.H == Hm and eng.w.dbl[-1]["pre_only"]
+    plan = eng.make_plan(shapes, mask)
+    assert plan.L == 11888 and plan.n_cur == 3840
+    so = lib.load()
+    Li = plan.L - LT
+    for M, N, K in ((Li, 3 * d, d), (Li, d, d), (Li, 4 * d, d), (Li, d, 4 * d),            # joint block, image stream
+                    (Li, 2 * d, d), (plan.n_cur, d, d), (plan.n_cur, 4 * d, d), (plan.n_cur, d, 4 * d)):   # last block (row-restricted)
+        assert so.pf_gemm_which(C.c_int(M), C.c_int(2), C.c_int(N), C.c_int(K)) == 8, (M, N, K)
+    ad = lib.AttnDesc()
+    so.pf_attention_workspace_bytes.restype = C.c_longlong
+    ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()),
+                                  int(so.pf_attention_workspace_bytes(C.c_int(2), C.c_int(Hm), C.c_int(plan.L))))
+    ad.Q = ad.O = ws.data_ptr()
+    ad.K = ad.Vt = ws.data_ptr()
+    ad.ldq = ad.ldk = ad.ldo = 3 * d
+    ad.strideQ = ad.strideO = plan.L * 3 * d
+    ad.B, ad.H, ad.L, ad.Lp, ad.Lt, ad.q_prescaled = 2, Hm, plan.L, plan.Lp, LT, 1
+    ad.workspace, ad.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert so.pf_attention_which(C.byref(ad)) == 64              # the joint block's in-place attention
+    ad.q_row_begin = plan.L - plan.n_cur
+    assert so.pf_attention_which(C.byref(ad)) == 64              # the last block: current frame's rows only
+    clips_d = [c.cuda() for c in clips]
+    ctx = eng.encode_context(enc)
+    dbg = {}
+    eng.skip_dead_rows = False
+    eng.forward_tokens(plan, clips_d, [386.0, 386.0], pooled, ctx, debug=dbg)
+    e_x = rel_l2(dbg["hidden_d0"].float().cpu()[:, LT:], inter["x_after_block0"])
+    e_f = rel_l2(dbg["hidden_final"].float().cpu()[:, LT:], inter["x_final"])
+    print(f"MMDiT L = 11888: image rows after the joint block {e_x:.3e}, after the context_pre_only block {e_f:.3e}")
+    assert e_x < 1.5e-2 and e_f < 2e-2
+    eng.skip_dead_rows = True                # production form: the last block computes the current frame's rows only
+    out = eng.forward(clips_d, enc, mask, pooled, t).cpu()
+    err = rel_l2(out, ref)
+    print(f"MMDiT d=1536 H=24 L=11888 (joint + context_pre_only block): forward rel-L2 vs oracle {err:.3e}")
     assert out.shape == ref.shape and err < 2e-2
