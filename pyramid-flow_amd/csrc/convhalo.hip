@@ -239,10 +239,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     // atomic per (filter, statistic) and 512-pixel tile.
     const bool do_stats = p.gn_stats != nullptr;       // workgroup-uniform
     float* const s_stat = (float*)smem;                // [wave 0..7][hsel][fc][e][2]: 8 x 64 x 2 floats = 4 KiB
-#pragma unroll
-    for (int hsel = 0; hsel < 2; ++hsel) {
+    // Every load of the epilogue (bias, the shortcut's pieces) is issued before the first store, and the bf16 results wait in
+    // registers (in place of the accumulators they came from) until both column halves are done: `res` may alias `Y` as far as
+    // the compiler knows, so in the one-pass form (load, add, store per piece: rounds 4) it kept every shortcut load behind the
+    // previous store and guarded it with s_waitcnt vmcnt(0) -- 16 dependent load + store round trips per tile.
+    u32x4_t outp[2][8];
+    auto out_off = [&](int hsel, int f, bool& ok) -> long long {
         const int n = 128 * nblk + 64 * wn + 32 * hsel + 8 * fc;
-        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
         // output placement of this lane's 8 filters (one group: Cg % 8 == 0): frame t st + pt (+ t_shift; < 0 = dropped),
         // pixel (y sh + ph, x sw + pw), channel cc
         const int gg = n / p.Cg, cc = n - gg * p.Cg;
@@ -250,26 +253,39 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
         const int pt = gg / shw, g2 = gg - pt * shw;
         const int ph = g2 / p.sw, pw = g2 - ph * p.sw;
         const int tf = t * p.st + pt + p.t_shift;
+        const int y = y0 + 4 * wm + (f >> 1), x = x0 + 16 * (f & 1) + fi;
+        ok = tf >= 0;
+        return p.out_base_off + (((long long)(tf < 0 ? 0 : tf) * p.Hop + (y * p.sh + ph)) * p.Wop + (x * p.sw + pw)) * p.Cout_pitch + cc;
+    };
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+        const int n = 128 * nblk + 64 * wn + 32 * hsel + 8 * fc;
+        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
+        u32x4_t rr[8];
+        if (p.res) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                bool ok;
+                rr[f] = *(const u32x4_t*)(p.res + out_off(hsel, f, ok));
+            }
+        }
         float gs[8], gq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) gs[e] = gq[e] = 0.f;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-            const int y = y0 + 4 * wm + (f >> 1), x = x0 + 16 * (f & 1) + fi;
-            const long long off = p.out_base_off + (((long long)(tf < 0 ? 0 : tf) * p.Hop + (y * p.sh + ph)) * p.Wop + (x * p.sw + pw)) * p.Cout_pitch + cc;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[f][2 * hsel][r] + b0[r]; v[4 + r] = acc[f][2 * hsel + 1][r] + b1[r]; }
             if (p.res) {
-                const u32x4_t rr = *(const u32x4_t*)(p.res + off);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += __uint_as_float(rr[e] << 16);
-                    v[2 * e + 1] += __uint_as_float(rr[e] & 0xffff0000u);
+                    v[2 * e] += __uint_as_float(rr[f][e] << 16);
+                    v[2 * e + 1] += __uint_as_float(rr[f][e] & 0xffff0000u);
                 }
             }
             const u32x4_t o = (u32x4_t){pack2_rne(v[0], v[1]), pack2_rne(v[2], v[3]), pack2_rne(v[4], v[5]), pack2_rne(v[6], v[7])};
-            if (tf >= 0) *(u32x4_t*)(p.Y + off) = o;
+            outp[hsel][f] = o;
             if (do_stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -294,6 +310,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
             }
         }
     }
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            bool ok;
+            const long long off = out_off(hsel, f, ok);
+            if (ok) *(u32x4_t*)(p.Y + off) = outp[hsel][f];
+        }
     if (do_stats) {
         BAR();
         if (tid < 256) {                              // (filter c, statistic k): add the four pixel-row waves of filter half wn_

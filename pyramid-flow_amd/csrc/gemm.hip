@@ -325,7 +325,7 @@ extern "C" int pf_gemm_set_policy(int force) {
     pf_gemm8p_set_tail_split(true);
     pf_gemm8p_set_tail_overhead(4);          // the measurement hook (400 + c) does not outlive a reset to automatic
     pf_gemm8p_set_stagger(0);
-    pf_gemm8p_set_epi_mode(3);
+    pf_gemm8p_set_epi_mode(1);
     return 0;
 }
 // Scratch that pays for this problem (pf_gemm_desc.workspace): 0 = none is used.  Large problems on the persistent 256 x 256

@@ -93,6 +93,11 @@ PF_DEVICE TileCoord tile_coord(const Args& p, int t, int tiles_m, int tiles_n) {
 template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // The LDS ring holds R = 8 units (two K-tiles); load slot g issues unit g + LA.  (A ring of 10 units = all 160 KiB of the
+    // CU with run-time ring positions was built and measured in round 5: no gain at the tile boundaries, and the position
+    // arithmetic in the load slots cost the main loop 4-9 %: profiles/r05_gemm8p_vs_r4_library_ring10.log.)
+    constexpr int R = 8, LA = R - 2;
+    constexpr int INFLIGHT = 2 * (R - 4);       // pieces of this wave that may still be in flight at the end of a load slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;          // wave tile: rows wm*128 .. +128, columns wn*64 .. +64
@@ -215,9 +220,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         return (long long)is_kt * (BK * 2);
     };
 
-    // issue unit j of the stream (kind j&3: 0 = A sub 0, 1 = B sub 0, 2 = B sub 1, 3 = A sub 1) into buffer (j>>2)&1
-    auto issue_unit = [&](int j) {
-        const int kind = j & 3;
+    // issue unit j of the stream into buffer (j >> 2) & 1 (kind = j & 3: 0 = A sub 0, 1 = B sub 0, 2 = B sub 1, 3 = A sub 1 --
+    // passed by the caller, where it is a compile-time constant: the per-lane offset arrays must not be indexed at run time)
+    auto issue_unit = [&](int j, const int kind) {
         char* buf = smem + ((j >> 2) & 1) * BUF_BYTES;
         if (kind == 0 || kind == 3) {
             const int s = kind == 0 ? 0 : 1;
@@ -330,7 +335,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     // batches of QFB row fragments per column half (all loads of a batch before its one drain, as for the residual).
     constexpr bool E_RES = (EPI & 1) != 0, E_F32 = (EPI & 2) != 0, E_ACT = (EPI & 4) != 0, E_QK = (EPI & 8) != 0;
     static_assert(!E_QK || (!E_RES && !E_F32 && !CONV), "the QK epilogue is a form of the plain / GELU flavour");
-    auto epilogue_tile = [&](int seq) {
+    // (j_next = index of the stream's next unit; returns the number of units it issued)
+    auto epilogue_tile = [&](int seq, int j_next) -> int {
+        // PRE-ISSUE (epi_mode bit 2): the two units whose ring regions died with this tile's last K-tile (its B sub 1 and A sub 1:
+        // every wave of both groups has read them) are requested NOW, in front of the tile's stores -- vmcnt retires loads and
+        // stores in issue order, so a unit issued behind the stores cannot be awaited before the store burst has drained; two
+        // more units in front of it are two more load slots of the next tile that run under the burst.
+        int n_pre = 0;
+        if (p.epi_mode & 4) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)            // units G + LA + 1, G + LA + 2 behind the tile's last load slot G = 4 gk + 3
+                if (j_next + k < U) { issue_unit(j_next + k, (LA + k) & 3); ++n_pre; }
+        }
         const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
         const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
         const bool mapped = CONV && p.om.mode == 1;
@@ -389,7 +405,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         const bool more_tiles = seq + 1 < n_my;
         // the next tile's bias: consumed after the stores are issued (acc_from_bias).  Requested AFTER the epilogue's first
         // drain (epi_mode bit 1) so that the drain does not wait for four fresh global loads
-        const bool bias_late = (p.epi_mode & 2) != 0;
+        // `early`: this wave's conversions wait for loads of their own (residual pieces, rope rows) or its stores are interleaved
+        // with them (fp32 output): the vector-memory queue is drained before the first conversion.  Otherwise (plain / GELU, and
+        // the V / MLP column blocks of the QK flavour) the drain comes after the conversions, directly before the first store:
+        // the units requested above land under the register work.
+        const bool early = E_RES || E_F32 || (E_QK && qk_reg != 0);
+        const bool bias_late = (p.epi_mode & 2) != 0 && early && !E_F32;
         if (FOLD_BIAS && more_tiles && !bias_late) load_bias(seq + 1);
         auto load_col_params = [&](int hsel) {
             const int n_raw = wave_n0 + 32 * hsel + 8 * fq;
@@ -468,11 +489,33 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         }
                     }
                 }
-                if ((hsel == 0 && f0 == 0) || E_RES || (E_QK && qk_reg)) {
+                if ((hsel == 0 && f0 == 0 && early) || E_RES || (E_QK && qk_reg)) {
                     // drains the DMA queue (see the main loop) and, for the residual / QK flavours, this batch's pieces
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PF_FENCE();
-                    if (hsel == 0 && f0 == 0 && FOLD_BIAS && more_tiles && bias_late) load_bias(seq + 1);
+                    // EVERY register a global load of this epilogue has filled is redefined here, right behind the drain that
+                    // covers it: the compiler does not see the asm drains and would otherwise guard the first use of each with
+                    // a wait of its own -- and where that use has sunk into a store's predicated block (the residual math of
+                    // the second column half does), with an s_waitcnt vmcnt(0) BEHIND the previous store: rounds 2-4 ran the
+                    // residual flavour's 16 stores as 16 store round trips.  After the redefinition nothing is pending in the
+                    // compiler's model and the stores go out back to back.
+                    if (E_RES) {
+#pragma unroll
+                        for (int f = 0; f < FB; ++f) asm volatile("" : "+v"(rbuf[f]));
+                        asm volatile("" : "+v"(rb0), "+v"(rb1), "+v"(gate4[hsel][0]), "+v"(gate4[hsel][1]));
+                    }
+                    if (E_QK) {
+                        if (qk_reg) {
+#pragma unroll
+                            for (int f = 0; f < FB; ++f) asm volatile("" : "+v"(qcs[f][0]), "+v"(qcs[f][1]));
+                            asm volatile("" : "+v"(qw0), "+v"(qw1));
+                        }
+                    }
+                    PF_FENCE();
+                    if (hsel == 0 && f0 == 0 && FOLD_BIAS && more_tiles) {
+                        if (bias_late) load_bias(seq + 1);
+                        else if (E_F32) asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3));   // (stores interleave below)
+                    }
                 }
 #pragma unroll
                 for (int fi = 0; fi < FB; ++fi) {
@@ -533,6 +576,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             }
         }
         if (!E_F32) {
+            if (!early) {       // nothing of this wave's DMA is in flight across its stores (see the main loop's skip_wait)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PF_FENCE();
+            }
+            // THE NEXT TILE'S BIAS HAS LANDED (every path above drained the queue after requesting it) -- but the compiler does
+            // not see the asm drains: it would guard the first use of nb0..3 (acc_from_bias, BEHIND the stores) with its own
+            // s_waitcnt vmcnt(0), i.e. every epilogue would wait for its whole store burst to retire (rounds 2-4 did: the
+            // "7 % for the stores" of the epilogue diagnosis).  Redefining the four registers here, in front of the stores,
+            // moves that wait to where the queue is empty anyway.
+            if (FOLD_BIAS) {
+                asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3));
+                PF_FENCE();
+            }
 #pragma unroll
             for (int hsel = 0; hsel < 2; ++hsel)
 #pragma unroll
@@ -548,6 +604,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     PF_FENCE();
                 }
         }
+        return n_pre;
     };
     // part of a split tail tile (always this workgroup's last segment): park the raw sums, lane-linear 16-byte pieces,
     // piece = accumulator index (row fragment f, column group c): slot `bid`, 32 KiB per wave
@@ -560,37 +617,41 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) *(f32x4v*)(pw + (f * 4 + c) * 1024) = acc[f][c];
     };
-    auto epilogue = [&](int seq) {
-        if (!CONV && tail_parks && seq >= n_full) { park(); return; }
-        epilogue_tile(seq);
+    auto epilogue = [&](int seq, int j_next) -> int {
+        if (!CONV && tail_parks && seq >= n_full) { park(); return 0; }
+        const int n_pre = epilogue_tile(seq, j_next);
         // the accumulators restart (from the next tile's bias; zero after / before a parked segment) only now:
         // re-initialising them while the packed results are still waiting for their stores would keep 128 + 64 registers
         // alive at once
         PF_FENCE();
         acc_from_bias();
+        return n_pre;
     };
 
-    // ---- prologue: units 0..5; units 0 and 1 (A sub 0, B sub 0 of the first K-tile: what load slot 0 reads) must have
+    // ---- prologue: units 0 .. LA - 1; units 0 and 1 (A sub 0, B sub 0 of the first K-tile: what load slot 0 reads) must have
     //      landed before the first barrier
     setup_issue_tile(0);
     {
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (j < U) issue_unit(j);
-        if (U >= 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        for (int j = 0; j < LA; ++j)
+            if (j < U) issue_unit(j, j & 3);
+        if (U >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PF_BAR();
     if (wm == 1) PF_BAR();                 // group 1 runs one barrier behind group 0
 
     // ---- main loop over the K-tiles of all tiles of this workgroup
-    // load slot g reads units <= g+1 and issues unit g+6; then: all units <= g+2 of this wave have landed.
-    int skip_wait = 0;                      // load slots after an epilogue whose wait is already covered
-    auto end_of_load_slot = [&](int g) {
-        if (g + 6 < U) {
-            issue_unit(g + 6);
+    // load slot g reads units <= g+1 and issues unit g + LA (unless the epilogue has issued it already); then: all units
+    // <= g+2 of this wave have landed.
+    // skip_wait: load slots after an epilogue whose wait is already covered (the epilogue drained every unit issued before
+    // its stores): LA - 2 + n_pre of them; during the first n_pre (skip_wait > LA - 2) the slot's unit is already issued.
+    int skip_wait = 0;
+    auto end_of_load_slot = [&](int g, const int ph) {          // g = 4 gk + ph
+        if (g + LA < U) {
+            if (skip_wait <= LA - 2) issue_unit(g + LA, (ph + LA) & 3);
             if (skip_wait > 0) --skip_wait;
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -607,21 +668,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         read_b(0, bs);
         PF_FENCE();
         read_a(0, bs);
-        end_of_load_slot(g);
+        end_of_load_slot(g, 0);
         mfma_quadrant(0, 0);
         PF_BAR();
         // phase 1: B sub 1 | (A0, B1)
         read_b(1, bs);
-        end_of_load_slot(g + 1);
+        end_of_load_slot(g + 1, 1);
         mfma_quadrant(0, 1);
         PF_BAR();
         // phase 2: A sub 1 | (A1, B1)
         read_a(1, bs);
-        end_of_load_slot(g + 2);
+        end_of_load_slot(g + 2, 2);
         mfma_quadrant(1, 1);
         PF_BAR();
         // phase 3: no fragment reads (B sub 0 is still resident) | (A1, B0)
-        end_of_load_slot(g + 3);
+        end_of_load_slot(g + 3, 3);
         mfma_quadrant(1, 0);
         // TILE BOUNDARY.  Group 1 runs one barrier behind group 0: with both epilogues in front of the loop's last barrier,
         // group 0's epilogue runs beside group 1's (short) load slot and group 1's beside group 0's next load slot -- one
@@ -636,9 +697,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
             // epilogue out of the counted waits
             PF_FENCE();
-            epilogue(c_tile);
+            const int n_pre = epilogue(c_tile, g + 4 + LA);
             PF_FENCE();
-            skip_wait = 4;
+            skip_wait = LA - 2 + n_pre;
             ++c_tile;
             c_kt = seg_begin(c_tile);
             c_end = seg_end(c_tile);
@@ -725,7 +786,7 @@ int g_num_cu = 0;
 bool g_tail_split = true;                  // pf_gemm_set_policy(-4) / (4): never / again split the tail tiles along K
 int g_tail_ov = 4;                         // fixed cost of a split in K-tile periods (tail_plan; pf_gemm_set_policy(400 + ov))
 int g_stagger = 0;                         // pf_gemm_set_policy(9) / (-9): desynchronised start on (290 cycles per K-tile and 1/8 step) / off
-int g_epi_mode = 3;                        // Args::epi_mode (pf_gemm_set_policy(1000 + m): measurement hook)
+int g_epi_mode = 1;                        // Args::epi_mode (pf_gemm_set_policy(1000 + m): measurement hook)
 
 template <bool CONV, int EPI>
 int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {

@@ -148,8 +148,13 @@ def test_halo_conv_upsampler_output_maps_equal_the_implicit_gemm(kind, Ci, Cg, T
     assert outs[True].abs().max() > 0
     d = (outs[True].float() - outs[False].float()).abs().max().item()
     assert rel_l2(outs[True].float().cpu(), outs[False].float().cpu()) < 3e-3 and d <= 2 ** -5 * outs[False].float().abs().max().item()
-    # exactly the same set of elements was written (borders, cache slots, a dropped first frame stay zero in both)
-    assert torch.equal(outs[True] != 0, outs[False] != 0)
+    # exactly the same set of elements was written (borders, cache slots, a dropped first frame stay zero in both); an element
+    # whose sum cancels to +-1e-7 may round to an exact bf16 zero in one summation order and not in the other (measured: one
+    # such element of 8.4 M): where the zero patterns differ, both values must be that small
+    diff = (outs[True] != 0) != (outs[False] != 0)
+    assert diff.sum().item() <= 8
+    assert outs[True][diff].float().abs().max().item() < 1e-5 if diff.any() else True
+    assert outs[False][diff].float().abs().max().item() < 1e-5 if diff.any() else True
     # ... and DIRECTLY against torch's fp32 conv3d of the same bf16 operands followed by the reference's rearranges
     # (filters in the reference's channel order: 'b (c p1 p2) t h w -> b c t (h p1) (w p2)' modeling_resnet.py:616,
     # 'b (c p) t h w -> b c (t p) h w' + the is_init_image first-frame drop :726-729); one op: rel-L2 <= 5e-3

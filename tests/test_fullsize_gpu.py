@@ -279,8 +279,12 @@ def test_mmdit_c4_length_forward_vs_oracle():
     so = lib.load()
     Li = plan.L - LT
     for M, N, K in ((Li, 3 * d, d), (Li, d, d), (Li, 4 * d, d), (Li, d, 4 * d),            # joint block, image stream
-                    (Li, 2 * d, d), (plan.n_cur, d, d), (plan.n_cur, 4 * d, d), (plan.n_cur, d, 4 * d)):   # last block (row-restricted)
+                    (Li, 2 * d, d), (plan.n_cur, 4 * d, d)):                                # last block: K|V of every row, MLP up
         assert so.pf_gemm_which(C.c_int(M), C.c_int(2), C.c_int(N), C.c_int(K)) == 8, (M, N, K)
+    # the last block's d-wide projections on the current frame's 3 840 rows are 180 tiles of 256 x 256 (< 3/4 of a round):
+    # a 256-row ping-pong kernel, not the 128 x 128 fallback
+    for M, N, K in ((plan.n_cur, d, d), (plan.n_cur, d, 4 * d)):
+        assert so.pf_gemm_which(C.c_int(M), C.c_int(2), C.c_int(N), C.c_int(K)) in (128, 192, 256), (M, N, K)
     ad = lib.AttnDesc()
     so.pf_attention_workspace_bytes.restype = C.c_longlong
     ws = ops._attention_workspace(torch.device(DEV, torch.cuda.current_device()),
