@@ -27,8 +27,9 @@ typedef struct ihipStream_t* pf_stream_t; /* == hipStream_t */
 const char* pf_last_error(void);
 /* ABI version of THIS header.  pf_version() returns the version the library was built with; a caller compares the two
  * before its first launch (a descriptor struct that grew -- 2 -> 3: pf_attn_desc.workspace / workspace_bytes,
- * pf_conv_desc.gn_stats / gn_C; 3 -> 4: pf_gemm_desc.qk_* -- would otherwise be read past its end). */
-#define PF_ABI_VERSION 4
+ * pf_conv_desc.gn_stats / gn_C; 3 -> 4: pf_gemm_desc.qk_*; 4 -> 5: pf_gemm_desc.qk_head_stride -- would otherwise be read
+ * past its end). */
+#define PF_ABI_VERSION 5
 int pf_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: 0 pf_gemm_desc, 1 pf_conv_desc, 2 pf_attn_desc,
  * 3 pf_attn_small_desc (-1 otherwise) -- lets a foreign-language binding (ctypes / cgo / JNI struct mirrors) verify its
@@ -80,6 +81,14 @@ typedef struct {
     const float* qk_rope; const float* qk_wq; const float* qk_wk;
     int qk_d, qk_q_col0, qk_k_col0, qk_row0;
     float qk_eps, qk_q_scale;
+    /* ABI 5 -- HEAD-MAJOR column layout of the fused projection (the sequence-parallel engine's [head][k | v | q][64], so that
+     * "the heads of rank p" is one contiguous column block of the exchange, modeling_flux_block.py:266-325): qk_head_stride > 0
+     * = columns per head (a multiple of 64); head h = columns [h qk_head_stride, (h + 1) qk_head_stride) for h < qk_d / 64,
+     * its K block at column qk_k_col0 and its Q block at qk_q_col0 INSIDE the head (multiples of 64; < 0 = absent).  With it
+     * the rank's K / Q leave the projection normed and rotated BEFORE the exchange (RMSNorm and RoPE are per row and per head:
+     * row r uses table row qk_row0 + r = the row's global index), and the received matrix needs no pass of its own.
+     * 0 = the two contiguous column blocks described above. */
+    int qk_head_stride;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
 /* bytes of pf_gemm_desc.workspace this problem can use (0 = it never splits) */
@@ -96,8 +105,17 @@ long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
  * upsamplers' output maps stay with the implicit GEMM / take the halo kernel; 9 / -9 = desynchronised start of the persistent
  * kernel's workgroups on / off (workgroups with a tile less than the busiest of their XCD wait out a fraction of a tile time, so
  * that the chip's 256 epilogues do not store in one burst; timing only, same bits; off by default); 400 + c (c = 0..199) = measurement hook: the
- * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0).  Default 0. */
+ * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0); 1000 + m = measurement hook: bits of the persistent
+ * kernel's epilogue schedule (bit 0: the two wave groups' epilogues run concurrently -- the default; bits 1, 2: the next tile's
+ * bias requested late / two operand units requested in front of the tile's stores: measured neutral, off);
+ * 2000 + R (R = 0 .. 128, rounded up to a multiple of 8) = the persistent kernel launches CUs - R workgroups and leaves R CUs
+ * (R / 8 per XCD) to kernels that must run BESIDE it -- the RCCL send / recv kernels of a sequence-parallel exchange
+ * (trainer_misc/communicate.py:7-26): a gemm8p workgroup owns its CU whole, so without a reservation an exchange in flight
+ * delays the launch by its own duration and an exchange queued behind the launch waits for its end
+ * (profiles/r05_comm_overlap_bench.log).  NOT reset by force = 0: the owner of the communicator sets and clears it.  Default 0. */
 int pf_gemm_set_policy(int force);
+/* workgroups of a persistent-kernel launch under the current reservation (CUs - R) */
+int pf_gemm_workgroups(void);
 /* which kernel pf_gemm_bf16 runs for (M rows per batch entry, batch, N, K) when the caller brings the scratch
  * pf_gemm_workspace_bytes asks for and no QK epilogue: 0 = gemm_kernel (128x128), 8 = gemm8p_kernel, BN > 0 =
  * gemm256_kernel<BN> */

@@ -269,6 +269,8 @@ void pf_gemm8p_set_tail_split(bool on);
 void pf_gemm8p_set_tail_overhead(int k_tiles);
 void pf_gemm8p_set_stagger(int cycles);
 void pf_gemm8p_set_epi_mode(int mode);
+void pf_gemm8p_set_reserved_cus(int n);
+int pf_gemm8p_workgroups();
 long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
 bool pf_conv_narrow_supports(const pf_conv_desc* d);                       // convnarrow.hip: <= 8 output channels (conv_out)
@@ -317,8 +319,9 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 9 || force == -9) { pf_gemm8p_set_stagger(force > 0 ? 290 : 0); return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force >= 1000 && force < 1064) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // measurement hook: Args::epi_mode bits
+    if (force >= 2000 && force <= 2128) { pf_gemm8p_set_reserved_cus(force - 2000); return 0; } // CUs the persistent launches leave to communication kernels
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c or 1000 + m");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c, 1000 + m or 2000 + R");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
@@ -357,6 +360,8 @@ static int gemm_route(const pf_gemm_desc* d, const Args& a) {
     if ((kind8 == 1 || (kind8 == 2 && ws8)) && pf_gemm8p_supports(a, false)) return 8;
     return pf_gemm256_pick((long long)d->M * d->batch, d->M, d->batch, d->N, gemm256_force());
 }
+// workgroups of a persistent launch = CUs of the device - the CUs reserved for communication kernels (policy 2000 + R)
+extern "C" int pf_gemm_workgroups(void) { return pf_gemm8p_workgroups(); }
 extern "C" int pf_gemm_which_desc(const pf_gemm_desc* d) {
     if (!d || d->M <= 0 || d->batch <= 0 || d->N <= 0 || d->K <= 0) return -100;
     Args a{};
@@ -381,21 +386,30 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     const bool qk = d->qk_d > 0;
     if (qk) {
         if (!d->qk_rope || !d->qk_wq || !d->qk_wk) return set_err("pf_gemm_bf16: qk_d > 0 needs qk_rope / qk_wq / qk_wk");
+        const int hs = d->qk_head_stride;
+        if (hs < 0 || hs % 64) return set_err("pf_gemm_bf16: qk_head_stride must be 0 or a multiple of 64");
+        if (hs > 0) {        // head-major: qk_d / 64 heads of hs columns, the K / Q blocks at fixed columns inside every head
+            if ((d->qk_d % 64) || (d->qk_q_col0 >= 0 && (d->qk_q_col0 % 64 || d->qk_q_col0 + 64 > hs)) ||
+                (d->qk_k_col0 >= 0 && (d->qk_k_col0 % 64 || d->qk_k_col0 + 64 > hs)) || (long long)(d->qk_d / 64) * hs > d->N)
+                return set_err("pf_gemm_bf16: head-major QK blocks must be 64-column aligned inside a head and the heads inside N");
+            if (a.gelu_from < (d->qk_d / 64) * hs) return set_err("pf_gemm_bf16: the activation columns overlap the heads");
+        } else {
         if ((d->qk_d % 64) || (d->qk_q_col0 >= 0 && d->qk_q_col0 % 64) || (d->qk_k_col0 >= 0 && d->qk_k_col0 % 64) ||
             (d->qk_q_col0 >= 0 && d->qk_q_col0 + d->qk_d > d->N) || (d->qk_k_col0 >= 0 && d->qk_k_col0 + d->qk_d > d->N))
             return set_err("pf_gemm_bf16: the QK blocks must be 64-column aligned and inside N");
-        if (d->flags & (PF_GEMM_GATE_RES | PF_GEMM_OUT_F32)) return set_err("pf_gemm_bf16: QK epilogue needs a plain bf16 output");
         if (a.gelu_from < d->N && ((d->qk_q_col0 >= 0 && a.gelu_from < d->qk_q_col0 + d->qk_d) || (d->qk_k_col0 >= 0 && a.gelu_from < d->qk_k_col0 + d->qk_d)))
             return set_err("pf_gemm_bf16: the activation columns overlap a QK block");
+        }
+        if (d->flags & (PF_GEMM_GATE_RES | PF_GEMM_OUT_F32)) return set_err("pf_gemm_bf16: QK epilogue needs a plain bf16 output");
         a.qk_rope = d->qk_rope; a.qk_wq = d->qk_wq; a.qk_wk = d->qk_wk;
         a.qk_d = d->qk_d; a.qk_q0 = d->qk_q_col0; a.qk_k0 = d->qk_k_col0; a.qk_row0 = d->qk_row0;
-        a.qk_eps = d->qk_eps; a.qk_qs = d->qk_q_scale;
+        a.qk_eps = d->qk_eps; a.qk_qs = d->qk_q_scale; a.qk_hs = hs;
     }
     // the separate pass for every kernel choice whose epilogue cannot do it (same arithmetic: common.h qk_rope8)
     auto qk_pass = [&]() -> int {
         return pf_qk_norm_rope(d->C, d->ldc, d->strideC, d->qk_q_col0, d->qk_k_col0, d->qk_wq, d->qk_wk, nullptr, nullptr,
                                d->qk_rope + (long long)d->qk_row0 * 64, d->batch, d->M, 0, d->qk_d / 64, d->qk_eps,
-                               d->qk_q_scale, 64, stream);
+                               d->qk_q_scale, d->qk_head_stride > 0 ? d->qk_head_stride : 64, stream);
     };
     // (a mid-size problem takes the persistent kernel only with its scratch: without it the older kernels fill the chip better)
     const int route = gemm_route(d, a);

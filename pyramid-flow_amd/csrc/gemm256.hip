@@ -251,58 +251,97 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const Args p) {
                 st[row * STR + j * 32 + frow] = acc[i][j][r];
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // Two passes over the strip's items: every global load of the strip (bias, gate, the residual pieces) is issued
+        // before its first store.  In the one-pass form (rounds 1-4) each item's loads stood behind the previous item's
+        // store -- `res` / `bias` may alias `C` for all the compiler knows -- and it guarded them with s_waitcnt vmcnt(0):
+        // three dependent load round trips + one store round trip per item.
+        // (COLFIX: 64 % CG == 0 -- BN = 128 / 256 -- a lane owns the same 8 columns in every item: ONE bias / gate set)
+        constexpr int NI = CG / 2;
+        constexpr bool COLFIX = 64 % CG == 0;
+        constexpr int NB = COLFIX ? 1 : NI;
+        long long coffs[NI];
+        bool oks[NI];
+        u32x4_t rr[NI];
+        f32x4_t bb0[NB], bb1[NB], gg0[NB], gg1[NB];
+        const bool has_res = (p.flags & PF_GEMM_GATE_RES) != 0;
 #pragma unroll
-        for (int it = 0; it < CG / 2; ++it) {
+        for (int it = 0; it < NI; ++it) {
             const int item = it * 64 + lane;
             const int row = item / CG, cgi = item - row * CG;
             const int m = wave_m0 + i * 32 + row;
             const int n = wave_n0 + cgi * 8;
+            bool ok = m < p.M && n < p.n_valid;
+            long long coff = 0;
+            if (ok) {
+                if (CONV && p.om.mode == 1) {
+                    const int hw = p.om.H * p.om.W;
+                    const int tt = m / hw, rem = m - tt * hw;
+                    const int hh = rem / p.om.W, ww = rem - hh * p.om.W;
+                    const int gg = n / p.om.Cg, cc = n - gg * p.om.Cg;
+                    const int shw = p.om.sh * p.om.sw;
+                    const int pt = gg / shw, g2 = gg - pt * shw;
+                    const int ph = g2 / p.om.sw, pw = g2 - ph * p.om.sw;
+                    const int tf = tt * p.om.st + pt + p.om.t_shift;
+                    ok = tf >= 0;
+                    coff = p.om.base_off +
+                           (((long long)(tf < 0 ? 0 : tf) * p.om.Hop + (hh * p.om.sh + ph)) * p.om.Wop + (ww * p.om.sw + pw)) *
+                               p.om.Cout_pitch + cc;
+                } else {
+                    coff = (long long)b * p.sC + (long long)m * p.ldc + n;
+                }
+            }
+            oks[it] = ok;
+            coffs[it] = coff;
+            const f32x4_t z4 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, o4 = (f32x4_t){1.f, 1.f, 1.f, 1.f};
+            rr[it] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (!COLFIX || it == 0) {
+                const int ib = COLFIX ? 0 : it;
+                const bool nok = COLFIX ? n < p.n_valid : ok;          // (COLFIX: the columns are valid or not for all items)
+                bb0[ib] = bb1[ib] = z4;
+                gg0[ib] = gg1[ib] = o4;
+                if (nok) {
+                    if (p.bias) { bb0[ib] = *(const f32x4_t*)(p.bias + n); bb1[ib] = *(const f32x4_t*)(p.bias + n + 4); }
+                    if (has_res && p.gate) {
+                        const float* gp = p.gate + (long long)b * p.gate_stride + n;
+                        gg0[ib] = *(const f32x4_t*)gp;
+                        gg1[ib] = *(const f32x4_t*)(gp + 4);
+                    }
+                }
+            }
+            if (ok && has_res) {
+                const long long roff =
+                    (CONV && p.om.mode == 1) ? coff : ((long long)b * p.sR + (long long)m * p.ldr + n);
+                rr[it] = *(const u32x4_t*)(p.res + roff);
+            }
+        }
+        // every loaded register is redefined HERE, outside the items' predicated blocks: the compiler then places its one wait
+        // for the loads above in front of this point, and none of its own behind a store (where vmcnt(0) would also wait for
+        // that store: gemm8p.hip, epilogue_tile, has the same statement for the same reason)
+#pragma unroll
+        for (int it = 0; it < NI; ++it) asm volatile("" : "+v"(rr[it]));
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) asm volatile("" : "+v"(bb0[ib]), "+v"(bb1[ib]), "+v"(gg0[ib]), "+v"(gg1[ib]));
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 64 + lane;
+            const int row = item / CG, cgi = item - row * CG;
+            const int n = wave_n0 + cgi * 8;
             const f32x4_t v0 = *(const f32x4_t*)(st + row * STR + cgi * 8);
             const f32x4_t v1 = *(const f32x4_t*)(st + row * STR + cgi * 8 + 4);
-            if (m >= p.M || n >= p.n_valid) continue;
+            if (!oks[it]) continue;
             float v[8];
-            if (p.bias) {
-                const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
+            const int ib = COLFIX ? 0 : it;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e] + b0[e]; v[4 + e] = v1[e] + b1[e]; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
-            }
+            for (int e = 0; e < 4; ++e) { v[e] = v0[e] + bb0[ib][e]; v[4 + e] = v1[e] + bb1[ib][e]; }
             if (n >= p.gelu_from) {
                 act8(v, p.flags);
             }
-            long long coff;
-            if (CONV && p.om.mode == 1) {
-                const int hw = p.om.H * p.om.W;
-                const int tt = m / hw, rem = m - tt * hw;
-                const int hh = rem / p.om.W, ww = rem - hh * p.om.W;
-                const int gg = n / p.om.Cg, cc = n - gg * p.om.Cg;
-                const int shw = p.om.sh * p.om.sw;
-                const int pt = gg / shw, g2 = gg - pt * shw;
-                const int ph = g2 / p.om.sw, pw = g2 - ph * p.om.sw;
-                const int tf = tt * p.om.st + pt + p.om.t_shift;
-                if (tf < 0) continue;
-                coff = p.om.base_off +
-                       (((long long)tf * p.om.Hop + (hh * p.om.sh + ph)) * p.om.Wop + (ww * p.om.sw + pw)) *
-                           p.om.Cout_pitch + cc;
-            } else {
-                coff = (long long)b * p.sC + (long long)m * p.ldc + n;
-            }
-            if (p.flags & PF_GEMM_GATE_RES) {
+            const long long coff = coffs[it];
+            if (has_res) {
                 float rv[8];
-                const long long roff =
-                    (CONV && p.om.mode == 1) ? coff : ((long long)b * p.sR + (long long)m * p.ldr + n);
-                unpack8(*(const u32x4_t*)(p.res + roff), rv);
-                if (p.gate) {
-                    const float* gp = p.gate + (long long)b * p.gate_stride + n;
-                    const f32x4_t g0 = *(const f32x4_t*)gp, g1 = *(const f32x4_t*)(gp + 4);
+                unpack8(rr[it], rv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] = rv[e] + g0[e] * v[e]; v[4 + e] = rv[4 + e] + g1[e] * v[4 + e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = rv[e] + v[e];
-                }
+                for (int e = 0; e < 4; ++e) { v[e] = rv[e] + gg0[ib][e] * v[e]; v[4 + e] = rv[4 + e] + gg1[ib][e] * v[4 + e]; }
             }
             if (p.out_scale != 1.f) {
 #pragma unroll

@@ -353,7 +353,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         // 0 = not a QK wave tile, 1 = K block, 2 = Q block (scalar)
         int qk_reg = 0;
         if (E_QK) {
-            if (p.qk_k0 >= 0 && wave_n0 >= p.qk_k0 && wave_n0 < p.qk_k0 + p.qk_d) qk_reg = 1;
+            if (p.qk_hs > 0) {               // head-major: [head][k | v | q ...]: the wave tile is one 64-wide block of one head
+                const int hd_ = wave_n0 / p.qk_hs, c_ = wave_n0 - hd_ * p.qk_hs;
+                if (hd_ * 64 < p.qk_d) qk_reg = c_ == p.qk_k0 ? 1 : (c_ == p.qk_q0 ? 2 : 0);
+            } else if (p.qk_k0 >= 0 && wave_n0 >= p.qk_k0 && wave_n0 < p.qk_k0 + p.qk_d) qk_reg = 1;
             else if (p.qk_q0 >= 0 && wave_n0 >= p.qk_q0 && wave_n0 < p.qk_q0 + p.qk_d) qk_reg = 2;
         }
         float qk_r[8];                                          // 1 / rms of the wave's rows (row fragment f, row frow)
@@ -783,6 +786,23 @@ __global__ __launch_bounds__(256) void gemm8p_tail_kernel(const Args p) {
 }
 
 int g_num_cu = 0;
+// CUs the persistent launches leave free (pf_gemm_set_policy(2000 + R), R a multiple of 8 = R / 8 per XCD; default 0).  A workgroup
+// of this kernel takes a CU whole (128 KiB of LDS, the whole register file): no other kernel's workgroup fits beside it, and
+// the tile assignment is static, so a communication kernel (RCCL send / recv of a sequence-parallel exchange, communicate.py:
+// 7-26) that is in flight when the launch starts either delays the workgroups of the CUs it holds -- the launch then ends
+// with THEIR tiles -- or, queued behind it, does not start before the launch ends.  With R CUs reserved both run side by
+// side at (256 - R) / 256 of the GEMM rate (tools/comm_overlap_bench.py measures the three cases).
+int g_reserve_cu = 0;
+static int cu_count() {
+    if (!g_num_cu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    const int n = g_num_cu - g_reserve_cu;
+    return n >= 64 ? n : g_num_cu;
+}
 bool g_tail_split = true;                  // pf_gemm_set_policy(-4) / (4): never / again split the tail tiles along K
 int g_tail_ov = 4;                         // fixed cost of a split in K-tile periods (tail_plan; pf_gemm_set_policy(400 + ov))
 int g_stagger = 0;                         // pf_gemm_set_policy(9) / (-9): desynchronised start on (290 cycles per K-tile and 1/8 step) / off
@@ -791,19 +811,14 @@ int g_epi_mode = 1;                        // Args::epi_mode (pf_gemm_set_policy
 template <bool CONV, int EPI>
 int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
     PF_SET_MAX_LDS_ONCE((gemm8p_kernel<CONV, EPI>), SMEM);
-    if (!g_num_cu) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (g_num_cu <= 0) g_num_cu = 256;
-    }
+    const int ncu = cu_count();
     Args a = a_in;
     const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
     // fewer tiles than CUs: with scratch the whole chip is launched anyway and the spare workgroups take K ranges of the
     // tiles (tail_plan with no full round: every tile is a tail tile), when that plan splits at all
-    const bool can_split = !CONV && g_tail_split && ws && ws_bytes >= (long long)g_num_cu * (256 << 10) && (g_num_cu & 7) == 0;
-    const bool mid = can_split && tiles < g_num_cu && pf_gemm8p_mid_split(tiles, a.K / BK) > 1;
-    const int grid = (tiles < g_num_cu && !mid) ? tiles : g_num_cu;
+    const bool can_split = !CONV && g_tail_split && ws && ws_bytes >= (long long)ncu * (256 << 10) && (ncu & 7) == 0;
+    const bool mid = can_split && tiles < ncu && pf_gemm8p_mid_split(tiles, a.K / BK) > 1;
+    const int grid = (tiles < ncu && !mid) ? tiles : ncu;
     // tail split: one 256-KiB slot of caller scratch per workgroup; the second launch covers the XCD with the most tail tiles
     a.part = nullptr;
     a.ksplit = grid;
@@ -843,7 +858,7 @@ bool pf_gemm8p_supports(const Args& a, bool conv) {
 // XCD with the most tiles); 1 = the split does not pay / is not possible
 int pf_gemm8p_mid_split(int tiles, int nk) {
     if (!g_tail_split) return 1;
-    const int ncu = g_num_cu > 0 ? g_num_cu : 256;
+    const int ncu = cu_count();
     if (tiles >= ncu || (ncu & 7)) return 1;
     const int clen = (tiles + 7) >> 3;
     return tail_plan(clen, ncu >> 3, nk, g_tail_ov).sp;
@@ -853,6 +868,8 @@ void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }
 void pf_gemm8p_set_tail_overhead(int k_tiles) { g_tail_ov = k_tiles; }
 void pf_gemm8p_set_stagger(int cycles) { g_stagger = cycles; }
 void pf_gemm8p_set_epi_mode(int mode) { g_epi_mode = mode; }
+void pf_gemm8p_set_reserved_cus(int n) { g_reserve_cu = n > 0 ? (n + 7) / 8 * 8 : 0; }
+int pf_gemm8p_workgroups() { return cu_count(); }
 
 // Scratch (bytes) with which pf_gemm8p_launch may split the tail tiles of a problem along K (one slot per workgroup).
 long long pf_gemm8p_workspace_bytes() { return 256ll * (256 << 10); }

@@ -45,6 +45,7 @@ struct Args {
     // QK-RMSNorm + RoPE of the K / Q column blocks in the epilogue (gemm8p flavour 8; pf_gemm_desc.qk_*): qk_d = 0 -> none
     const float* qk_rope; const float* qk_wq; const float* qk_wk;
     int qk_d, qk_q0, qk_k0, qk_row0;
+    int qk_hs;               // > 0: head-major columns, qk_hs per head; the K / Q blocks start at qk_k0 / qk_q0 inside every head
     float qk_eps, qk_qs;
     double* gn_stats;        // conv kernels of gemm256.hip: [frame][gn_C][2] (sum, sum of squares) of the OUTPUT, accumulated in
     int gn_C;                //   the epilogue for the GroupNorm that reads it (nullptr = none)

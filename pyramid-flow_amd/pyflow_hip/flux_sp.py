@@ -158,6 +158,19 @@ class FluxEngineSP(FluxEngine):
             if rows:
                 ops.ln_modulate(hidden, xn, (mod, sh), (mod, sc), d, B, rows, Ld, Ld, d, d, nm, x_off=x_off, y_off=x_off)
 
+        # QK-RMSNorm + RoPE (flux_block.py:846-858) are per row and per head: since round 5 a rank's K / Q leave its OWN
+        # projection normed and rotated (pf_gemm_desc.qk_* with the head-major column layout: in the persistent kernel's
+        # epilogue, by the library's separate pass for the small launches) -- BEFORE the exchange; the received matrix goes
+        # straight into the attention.  `fuse_qk = False`: the round 3-4 form (one pass over the received matrix).
+        fuse = self.fuse_qk
+
+        def qk_of(wq, wk, row0):
+            """descriptor part for a K|V|Q projection whose row 0 is global row `row0`"""
+            if not fuse:
+                return None
+            return dict(rope=plan.rope, wq=wq, wk=wk, d=d, k_col0=0, q_col0=128, head_stride=lay.HEAD_COLS, row0=row0,
+                        eps=w.qk_eps, q_scale=qs)
+
         def attend(ld, norms, overlap=None, q_row_begin=0):
             """big (first 3d columns, head-major) -> obuf = attention output of my heads for all rows.
             `overlap`: work that does not depend on the exchange, queued while the all-to-all is in flight."""
@@ -167,8 +180,9 @@ class FluxEngineSP(FluxEngine):
             if h is not None:
                 h.wait()
             if mh:
-                ops.qk_norm_rope(recv1, B * mc, mc, 128, 0, *norms, plan.rope, B, L, Lt, mh, q_scale=qs,
-                                 head_stride=lay.HEAD_COLS, eps=w.qk_eps)
+                if not fuse:
+                    ops.qk_norm_rope(recv1, B * mc, mc, 128, 0, *norms, plan.rope, B, L, Lt, mh, q_scale=qs,
+                                     head_stride=lay.HEAD_COLS, eps=w.qk_eps)
                 # V = columns 64 .. 127 of every head's [k | v | q] block of the received matrix: read token-major
                 ops.attention(recv1, recv1, None, obuf, 128, 0, 0, B * mc, mc, B, mh, L, Lp, Lt, plan, scale,
                               q_prescaled=True, head_stride_qk=lay.HEAD_COLS, ldo=B * mh * 64, o_bstride=mh * 64,
@@ -189,10 +203,13 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 6 * d, mb + 7 * d)
             if n_img:
                 ops.gemm(xn, blk["kvq_img"][0], big, n_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
-                         strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, tail_workspace=ws_img, split_small=self.split_small)
-            if n_txt:
+                         strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, tail_workspace=ws_img, split_small=self.split_small,
+                         qk=qk_of(blk["norm_q"], blk["norm_k"], lay.r0 + n_txt))
+            if n_txt:         # text rows: the added-projection gains (norm_added_q / k; the image gains where the model has none)
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
-                         strideA=Ld, strideC=L3, workspace=ws_txt)
+                         strideA=Ld, strideC=L3, workspace=ws_txt,
+                         qk=qk_of(blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"],
+                                  blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"], lay.r0))
             norms = (blk["norm_q"], blk["norm_k"], blk["norm_added_q"], blk["norm_added_k"])
             attend(3 * d, norms, q_row_begin=r_cur if tail else 0)
             h2 = self._exchange_out_start(lay, obuf, B, recv2)
@@ -235,7 +252,8 @@ class FluxEngineSP(FluxEngine):
             # K|V|Q first, then the MLP branch (proj_mlp + GELU, flux_block.py:921-922) while the exchanges fly
             if nloc:
                 ops.gemm(xn, blk["kvqm"][0], big, nloc, 3 * d, d, d, d, 7 * d, bias=blk["kvqm"][1], batch=B, strideA=Ld,
-                         strideC=L7, tail_workspace=ws_img, split_small=self.split_small)
+                         strideC=L7, tail_workspace=ws_img, split_small=self.split_small,
+                         qk=qk_of(blk["norm_q"], blk["norm_k"], lay.r0))
 
             def mlp_cols(c0, nc, blk=blk, i0=i0, n_act=n_act):
                 if n_act > 0 and nc > 0:
@@ -272,7 +290,7 @@ class FluxEngineSP(FluxEngine):
         n_mod = plan.B * self.w.n_mod
         for _ in range(2):
             ms = self._buf("mod_fixed", n_mod, torch.float32)
-            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm), self.split_small)
+            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm), self.split_small, self.fuse_qk)
             ent = getattr(plan, "_sp_list", None)
             if ent is not None and ent[0] == key:
                 break

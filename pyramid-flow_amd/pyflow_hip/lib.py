@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
                 ("qk_rope", C.c_void_p), ("qk_wq", C.c_void_p), ("qk_wk", C.c_void_p),
                 ("qk_d", C.c_int), ("qk_q_col0", C.c_int), ("qk_k_col0", C.c_int), ("qk_row0", C.c_int),
-                ("qk_eps", C.c_float), ("qk_q_scale", C.c_float)]
+                ("qk_eps", C.c_float), ("qk_q_scale", C.c_float), ("qk_head_stride", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -63,7 +63,7 @@ class AttnSmallDesc(C.Structure):
                 ("bias", C.c_void_p), ("key_mask", C.c_void_p), ("causal", C.c_int), ("scale", C.c_float)]
 
 
-ABI_VERSION = 4          # PF_ABI_VERSION of include/pyflow_hip.h
+ABI_VERSION = 5          # PF_ABI_VERSION of include/pyflow_hip.h
 GEMM_GATE_RES = 1
 GEMM_OUT_F32 = 2
 GEMM_ACT_QUICK_GELU = 4
@@ -71,7 +71,7 @@ GEMM_ACT_GELU_ERF = 8
 
 # every symbol include/pyflow_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "pf_last_error", "pf_version", "pf_struct_size", "pf_gemm_bf16", "pf_gemm_set_policy", "pf_gemm_which", "pf_gemm_which_desc", "pf_gemm_workspace_bytes", "pf_conv3d_bf16", "pf_conv3d_fuses_gn_stats", "pf_conv3d_which", "pf_attention_bf16", "pf_attention_workspace_bytes", "pf_attention_which", "pf_v_transpose",
+    "pf_last_error", "pf_version", "pf_struct_size", "pf_gemm_bf16", "pf_gemm_set_policy", "pf_gemm_which", "pf_gemm_which_desc", "pf_gemm_workgroups", "pf_gemm_workspace_bytes", "pf_conv3d_bf16", "pf_conv3d_fuses_gn_stats", "pf_conv3d_which", "pf_attention_bf16", "pf_attention_workspace_bytes", "pf_attention_which", "pf_v_transpose",
     "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
     "pf_copy_rows", "pf_sp_relayout", "pf_renoise_upsample", "pf_avgpool2",
     "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_shift_caches", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",

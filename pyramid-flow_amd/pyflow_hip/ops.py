@@ -52,7 +52,7 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
     shared by overlapping launches.  tail_workspace: the same, but handed over only to problems that run the persistent
     256 x 256 kernel (pf_gemm_which == 8): the compute stream's scratch, which leaves the summation order of small
     problems what it is without scratch.
-    qk: dict(rope, wq, wk, d, q_col0, k_col0, row0, eps, q_scale) -- QK-RMSNorm + RoPE of the K / Q column blocks of C as part
+    qk: dict(rope, wq, wk, d, q_col0, k_col0, row0, eps, q_scale[, head_stride]) -- QK-RMSNorm + RoPE of the K / Q column blocks of C as part
     of this GEMM (pf_gemm_desc.qk_*: in the persistent kernel's epilogue, else by the library's separate pass)."""
     lib = L.load()
     esz_c = 4 if (flags & GEMM_OUT_F32) else 2
@@ -78,6 +78,7 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
         d.qk_rope, d.qk_wq, d.qk_wk = qk["rope"].data_ptr(), qk["wq"].data_ptr(), qk["wk"].data_ptr()
         d.qk_d, d.qk_q_col0, d.qk_k_col0, d.qk_row0 = qk["d"], qk.get("q_col0", -1), qk.get("k_col0", -1), qk.get("row0", 0)
         d.qk_eps, d.qk_q_scale = qk.get("eps", 1e-6), qk.get("q_scale", 1.0)
+        d.qk_head_stride = qk.get("head_stride", 0)
     rec = RECORDER
     if rec is not None:
         check(lib.pf_cmdlist_gemm(rec.h, C.byref(d), C.c_int(rec.slot)))

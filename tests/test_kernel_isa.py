@@ -1,0 +1,93 @@
+"""ISA lint of the hand-scheduled kernels (CPU tier: hipcc cross-compiles gfx950 without a GPU).
+
+The persistent GEMM and the halo convolution order their vector-memory traffic with COUNTED `s_waitcnt vmcnt(N)` written as
+inline asm.  Two things the compiler can silently add break that scheme without breaking a single result:
+  * a scratch access (spill) -- a vector-memory operation the counts do not know about;
+  * a wait of its own in front of the first use of a register that a global load filled: where that use has sunk behind the
+    epilogue's stores, it becomes an `s_waitcnt vmcnt(0)` that waits for the tile's whole store burst (rounds 2-4 shipped
+    exactly that: gemm8p's residual flavour issued its 16 stores as 16 load + store round trips, the bias-folding flavours
+    drained every tile's stores before touching the next tile; round 5 found it in the ISA, not in a profile).
+This test compiles the two sources to ISA and checks, per kernel: no scratch, and the tile's stores form ONE run of >= 16
+`global_store_dwordx4` with no `s_waitcnt vmcnt` between them and none between the last store and the next barrier.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pyramid-flow_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _isa(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                    "-Wno-unused-value", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_Z\w+):.*?^\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
+        body = text[m.start():m.start(2)]
+        meta = m.group(2)
+        kernels[m.group(1)] = (body, meta)
+    return kernels
+
+
+def _store_runs(body):
+    """lengths of the runs of global_store_dwordx4 that no s_waitcnt vmcnt interrupts, and whether a vmcnt wait stands between
+    the last store of the longest run and the next s_barrier"""
+    ops = []
+    for ln in body.splitlines():
+        t = ln.split(";")[0].strip()
+        if t.startswith("global_store_dwordx4"):
+            ops.append("S")
+        elif t.startswith("s_waitcnt") and "vmcnt" in t:
+            ops.append("W")
+        elif t.startswith("s_barrier"):
+            ops.append("B")
+        elif t.startswith(("global_load", "global_atomic", "buffer_", "scratch_")):
+            ops.append("L")
+    runs, cur = [], 0
+    for i, o in enumerate(ops):
+        if o == "S":
+            cur += 1
+        else:                                  # a wait, a load or a barrier ends the run; `i` = the op that follows it
+            if cur:
+                runs.append((cur, i))
+            cur = 0
+    if cur:
+        runs.append((cur, len(ops)))
+    # (the listing is textual: the park path's 32 fp32 stores sit in front of the epilogue's loads without falling through
+    #  into them, so "clean" is asked of SOME full run, and "no short runs" of all of them)
+    clean = []
+    for n, end in runs:
+        tail = ops[end:]
+        clean.append(n >= 16 and "W" not in (tail[:tail.index("B")] if "B" in tail else tail))
+    return [r for r, _ in runs], clean
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gemm8p_epilogue_stores_are_not_guarded_by_compiler_waits(tmp_path):
+    ks = {k: v for k, v in _isa("gemm8p.hip", tmp_path).items() if "gemm8p_kernel" in k}
+    assert len(ks) >= 6                      # conv, QK (12), residual (1), fp32 (2), GELU (4), plain (0)
+    for name, (body, meta) in ks.items():
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta), f"{name}: scratch in a kernel with counted waits"
+        assert "scratch_" not in body, name
+        runs, clean = _store_runs(body)
+        # the tile's stores go out in whole blocks of 16 (one per (row fragment, column half)): a shorter run is a store that
+        # something -- a wait, a load -- separates from its neighbours
+        assert runs and all(r % 16 == 0 for r in runs), (name, runs)
+        assert any(clean), f"{name}: a vmcnt wait between the tile's last store and the next barrier"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_halo_conv_epilogue_loads_before_stores(tmp_path):
+    ks = {k: v for k, v in _isa("convhalo.hip", tmp_path).items() if "conv_halo128_kernel" in k}
+    assert ks
+    for name, (body, meta) in ks.items():
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta), name
+        runs, _ = _store_runs(body)
+        assert runs and all(r % 16 == 0 for r in runs), (name, runs)

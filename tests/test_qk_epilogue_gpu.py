@@ -87,6 +87,52 @@ def test_fused_qk_epilogue_equals_gemm_then_separate_pass(case, policy):
     assert torch.equal(fused[:, :, keep], plain[:, :, keep])
 
 
+@pytest.mark.parametrize("policy", [8, 0, -8])
+@pytest.mark.parametrize("M,d,extra", [(1500, 1920, 0), (700, 256, 512)])
+def test_fused_qk_epilogue_head_major_layout(policy, M, d, extra):
+    """ABI 5: the sequence-parallel engine's head-major projection columns [head][k | v | q][64] (qk_head_stride = 192): K at
+    column 0 and Q at column 128 of every head -- normed and rotated by the GEMM BEFORE the exchange (flux_sp.py).  Same bits
+    as "plain GEMM, then pf_qk_norm_rope with head_stride = 192"; the V blocks and any columns behind the heads (the MLP
+    branch) are the plain projection."""
+    from pyflow_hip import ops
+    B, K, H = 2, (1920 if d == 1920 else 256), d // 64
+    N = 3 * d + extra
+    row0 = 77
+    A = _mk((B, M, K), 11).to(torch.bfloat16).to(DEV)
+    W = _mk((N, K), 12, 0.06).to(torch.bfloat16).to(DEV)
+    bias = _mk((N,), 13).to(DEV)
+    wq = (1.0 + 0.3 * _mk((64,), 14)).to(DEV)
+    wk = (1.0 + 0.3 * _mk((64,), 15)).to(DEV)
+    rope = _rope_table(row0 + M, 16)
+    qs = 0.125 * ops.LOG2E
+    gelu_from = 3 * d if extra else -1
+    ops.gemm_set_policy(policy)
+    try:
+        fused = torch.zeros(B, M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(A, W, fused, M, N, K, K, K, N, bias=bias, batch=B, strideA=M * K, strideC=M * N, gelu_from=gelu_from,
+                 qk=dict(rope=rope, wq=wq, wk=wk, d=d, q_col0=128, k_col0=0, head_stride=192, row0=row0, eps=1e-6, q_scale=qs))
+        plain = torch.zeros_like(fused)
+        ops.gemm(A, W, plain, M, N, K, K, K, N, bias=bias, batch=B, strideA=M * K, strideC=M * N, gelu_from=gelu_from)
+    finally:
+        ops.gemm_set_policy(0)
+    sep = plain.clone()
+    ops.qk_norm_rope(sep, N, M * N, 128, 0, wq, wk, None, None, rope[row0:], B, M, 0, H, q_scale=qs, head_stride=192)
+    assert torch.equal(fused, sep), f"head-major: fused != separate pass, rel {rel_l2(fused.float(), sep.float()):.3e}"
+    hm = plain[:, :, :3 * d].view(B, M, H, 3, 64)
+    fm = fused[:, :, :3 * d].view(B, M, H, 3, 64)
+    assert torch.equal(fm[:, :, :, 1], hm[:, :, :, 1])                     # V blocks untouched
+    assert not torch.equal(fm[:, :, :, 0], hm[:, :, :, 0]) and not torch.equal(fm[:, :, :, 2], hm[:, :, :, 2])
+    if extra:
+        assert torch.equal(fused[:, :, 3 * d:], plain[:, :, 3 * d:])
+    # fp32 restatement of one head's K block
+    blk = hm[:, :, 3, 0].float()
+    n = blk * torch.rsqrt(blk.pow(2).mean(-1, keepdim=True) + 1e-6) * wk
+    cs = rope[row0:row0 + M]
+    x0, x1 = n[..., 0::2], n[..., 1::2]
+    ref = torch.stack([cs[None, :, :, 0] * x0 - cs[None, :, :, 1] * x1, cs[None, :, :, 1] * x0 + cs[None, :, :, 0] * x1], dim=-1).reshape(B, M, 64)
+    assert rel_l2(fm[:, :, 3, 0].float(), ref) < 4e-3
+
+
 def test_forward_identical_with_and_without_the_fused_epilogue():
     from pyflow_hip import synth
     from pyflow_hip.flux import FluxEngine
