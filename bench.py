@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--tiny-model", action="store_true", help="tiny random model (plumbing check, not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-period", type=int, default=7)
+    ap.add_argument("--group-text", default="auto", choices=["auto", "on", "off"],
+                    help="double blocks: the text stream's GEMMs inside the image stream's persistent launches (pf_gemm_desc.A2 ..., "
+                         "FluxEngine.group_text) -- auto = the engine's default (A/B switch)")
     ap.add_argument("--no-overlap-text", action="store_true",
                     help="run the double blocks' text stream on the compute stream instead of the side stream (A/B switch)")
     ap.add_argument("--launch-mode", default="graph", choices=["eager", "list", "graph"],
@@ -397,6 +400,8 @@ def main():
             pipe.dit.launch_mode = args.launch_mode
         if args.no_overlap_text:
             pipe.dit.overlap_text = False
+        if args.group_text != "auto" and hasattr(pipe.dit, "group_text"):
+            pipe.dit.group_text = args.group_text == "on"
         sp = SampledProfiler(pipe, args.profile_period)
         pipe.phase_times = None
 

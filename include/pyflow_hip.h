@@ -27,9 +27,9 @@ typedef struct ihipStream_t* pf_stream_t; /* == hipStream_t */
 const char* pf_last_error(void);
 /* ABI version of THIS header.  pf_version() returns the version the library was built with; a caller compares the two
  * before its first launch (a descriptor struct that grew -- 2 -> 3: pf_attn_desc.workspace / workspace_bytes,
- * pf_conv_desc.gn_stats / gn_C; 3 -> 4: pf_gemm_desc.qk_*; 4 -> 5: pf_gemm_desc.qk_head_stride -- would otherwise be read
- * past its end). */
-#define PF_ABI_VERSION 5
+ * pf_conv_desc.gn_stats / gn_C; 3 -> 4: pf_gemm_desc.qk_*; 4 -> 5: pf_gemm_desc.qk_head_stride; 5 -> 6: the second
+ * problem of a grouped GEMM launch -- would otherwise be read past its end). */
+#define PF_ABI_VERSION 6
 int pf_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: 0 pf_gemm_desc, 1 pf_conv_desc, 2 pf_attn_desc,
  * 3 pf_attn_small_desc (-1 otherwise) -- lets a foreign-language binding (ctypes / cgo / JNI struct mirrors) verify its
@@ -89,6 +89,22 @@ typedef struct {
      * row r uses table row qk_row0 + r = the row's global index), and the received matrix needs no pass of its own.
      * 0 = the two contiguous column blocks described above. */
     int qk_head_stride;
+    /* ABI 6 -- GROUPED launch: a SECOND problem C2 = epi(A2 . W2^T) with the same N, K, lda / ldw / ldc / ldr, batch count,
+     * flags, gelu_from, gate_stride and QK layout, its own operands, row count M2 (> 0 = present) and batch strides, and -- with
+     * a QK epilogue -- its own gains and first RoPE row.  The double-stream blocks run every projection twice, once per
+     * stream, with different weights on different rows (flux_block.py:816-835 to_q/k/v vs add_q/k/v_proj, :868-872 to_out vs
+     * to_add_out, :1022-1036 ff vs ff_context; text = 128 rows per prompt): where the persistent 256 x 256 kernel serves the
+     * first problem, the second one's tiles are appended to the SAME launch's tile list (no second launch, no side stream,
+     * no K-split scratch for the skinny problem); any other kernel choice runs the two problems as two launches.  On whole
+     * tiles the result of either problem does not depend on the grouping (a tile is computed by one workgroup in K order
+     * either way); with the tail split (workspace) the launch's tile count decides WHICH tiles are split, so grouped and
+     * separate results differ in fp32 summation order there, as split and unsplit results do. */
+    const void* A2; const void* W2; void* C2;
+    const float* bias2; const void* res2; const float* gate2;
+    int M2;
+    long long strideA2, strideC2, strideR2;
+    const float* qk_wq2; const float* qk_wk2;
+    int qk_row0_2;
 } pf_gemm_desc;
 int pf_gemm_bf16(const pf_gemm_desc* d, pf_stream_t stream);
 /* bytes of pf_gemm_desc.workspace this problem can use (0 = it never splits) */

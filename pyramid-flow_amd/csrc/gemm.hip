@@ -362,15 +362,39 @@ static int gemm_route(const pf_gemm_desc* d, const Args& a) {
 }
 // workgroups of a persistent launch = CUs of the device - the CUs reserved for communication kernels (policy 2000 + R)
 extern "C" int pf_gemm_workgroups(void) { return pf_gemm8p_workgroups(); }
+// a grouped descriptor is served as ONE launch only by the persistent kernel (decided on the first problem)
+static bool grouped_ok(const pf_gemm_desc* d) {
+    Args a{};
+    a.N = d->N; a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
+    return d->K > 0 && d->K % BK == 0 && gemm_route(d, a) == 8;
+}
 extern "C" int pf_gemm_which_desc(const pf_gemm_desc* d) {
     if (!d || d->M <= 0 || d->batch <= 0 || d->N <= 0 || d->K <= 0) return -100;
     Args a{};
     a.N = d->N; a.gelu_from = d->gelu_from < 0 ? d->N : d->gelu_from; a.flags = d->flags;
     return gemm_route(d, a);
 }
+// the second problem of a grouped descriptor as a descriptor of its own (what runs when the grouping is not taken)
+static pf_gemm_desc second_problem(const pf_gemm_desc* d) {
+    pf_gemm_desc e = *d;
+    e.A = d->A2; e.W = d->W2; e.C = d->C2; e.bias = d->bias2; e.res = d->res2; e.gate = d->gate2;
+    e.M = d->M2; e.strideA = d->strideA2; e.strideC = d->strideC2; e.strideR = d->strideR2;
+    e.qk_wq = d->qk_wq2; e.qk_wk = d->qk_wk2; e.qk_row0 = d->qk_row0_2;
+    e.M2 = 0; e.A2 = e.W2 = nullptr; e.C2 = nullptr;
+    return e;
+}
+static bool grouped_ok(const pf_gemm_desc* d);
 extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     if (!d || !d->A || !d->W || !d->C) return set_err("pf_gemm_bf16: null operand");
     if (d->M <= 0 || d->batch <= 0) return set_err("pf_gemm_bf16: empty problem");
+    if (d->M2 < 0 || (d->M2 > 0 && (!d->A2 || !d->W2 || !d->C2))) return set_err("pf_gemm_bf16: grouped launch: bad second problem");
+    if (d->M2 > 0 && !grouped_ok(d)) {      // not a launch of the persistent kernel: the two problems as two launches
+        pf_gemm_desc first = *d;
+        first.M2 = 0;
+        const pf_gemm_desc second = second_problem(d);
+        const int rc = pf_gemm_bf16(&first, stream);
+        return rc ? rc : pf_gemm_bf16(&second, stream);
+    }
     if (d->K % BK != 0 || d->K <= 0) return set_err("pf_gemm_bf16: K must be a positive multiple of 64");
     if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8)) return set_err("pf_gemm_bf16: leading dims must be multiples of 8");
     if ((d->flags & PF_GEMM_GATE_RES) && !d->res) return set_err("pf_gemm_bf16: GATE_RES needs res");
@@ -414,6 +438,13 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     // (a mid-size problem takes the persistent kernel only with its scratch: without it the older kernels fill the chip better)
     const int route = gemm_route(d, a);
     const bool g8 = route == 8;
+    if (d->M2 > 0) {                         // (grouped_ok: route == 8)
+        if ((d->flags & PF_GEMM_GATE_RES) && !d->res2) return set_err("pf_gemm_bf16: GATE_RES needs res2");
+        if (qk && (!d->qk_wq2 || !d->qk_wk2)) return set_err("pf_gemm_bf16: grouped QK epilogue needs qk_wq2 / qk_wk2");
+        a.pr[1] = Prob{(const bf16_t*)d->A2, (const bf16_t*)d->W2, d->C2, d->bias2, (const bf16_t*)d->res2, d->gate2,
+                       d->strideA2, d->strideC2, d->strideR2, d->qk_wq2, d->qk_wk2, d->M2, d->qk_row0_2};
+        a.tiles2_m = (d->M2 + 255) / 256;
+    }
     const int bn256 = g8 ? 0 : route;
     if (!g8 && !bn256 && d->N % BN != 0)
         return set_err("pf_gemm_bf16: N must be a multiple of 128 (or of 192 with the 256x192 kernel)");

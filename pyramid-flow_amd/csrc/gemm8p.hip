@@ -56,7 +56,7 @@ constexpr int GROUP_M = 4;
         PF_FENCE();                       \
     } while (0)
 
-struct TileCoord { int b, m0, n0; };
+struct TileCoord { int b, m0, n0, g; };           // g = problem of a grouped launch (0 / 1)
 
 // How the `clen` tiles of one XCD's chunk are dealt to its `nslot` workgroups: n_full whole rounds, then r tail tiles, each
 // split along K over sp workgroups (sp = 1: one whole tile for each of the first r workgroups, the round-2 behaviour):
@@ -77,6 +77,13 @@ __host__ __device__ inline TailPlan tail_plan(int clen, int nslot, int nk, int o
 }
 
 PF_DEVICE TileCoord tile_coord(const Args& p, int t, int tiles_m, int tiles_n) {
+    const int T1 = tiles_m * p.batch * tiles_n;
+    if (t >= T1) {                      // second problem of a grouped launch: few row tiles, column-major walk (shared W panels)
+        const int t2 = t - T1, TM2 = p.tiles2_m * p.batch;
+        const int tn = t2 / TM2, tmm = t2 - tn * TM2;
+        const int b = tmm / p.tiles2_m, tm = tmm - b * p.tiles2_m;
+        return TileCoord{b, tm * BM, tn * BN, 1};
+    }
     const int TM = tiles_m * p.batch;
     const int GM = p.group_m > 0 ? p.group_m : GROUP_M;
     const int group_sz = GM * tiles_n;
@@ -87,7 +94,7 @@ PF_DEVICE TileCoord tile_coord(const Args& p, int t, int tiles_m, int tiles_n) {
     const int tn = r_in / gm;
     const int tmm = first_m + (r_in - tn * gm);
     const int b = tmm / tiles_m, tm = tmm - b * tiles_m;
-    return TileCoord{b, tm * BM, tn * BN};
+    return TileCoord{b, tm * BM, tn * BN, 0};
 }
 
 template <bool CONV, int EPI>
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     //      workgroups take the chunk's tiles round-robin, so the tiles in flight on one XCD are neighbours (shared
     //      operand panels in that XCD's L2).
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int T = tiles_m * p.batch * tiles_n;
+    const int T = (tiles_m + (CONV ? 0 : p.tiles2_m)) * p.batch * tiles_n;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int nslot = (nwg - xcd + 7) >> 3;
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 
     auto setup_issue_tile = [&](int seq) {
         const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
-        const bf16_t* A = p.A + (long long)tc.b * p.sA;
+        const Prob& q = p.pr[CONV ? 0 : tc.g];
+        const bf16_t* A = q.A + (long long)tc.b * q.sA;
         long long base_el;                          // element offset of the tile's first row
         if (CONV) {
             const int hw = p.cg.H * p.cg.W;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             base_el = (long long)tc.m0 * p.lda;
         }
         is_abase = (const char*)(A + base_el);
-        is_wbase = (const char*)(p.W + (long long)tc.n0 * p.ldw);
+        is_wbase = (const char*)(q.W + (long long)tc.n0 * p.ldw);
         int ln = lane;
         asm volatile("" : "+v"(ln));
 #pragma unroll
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             for (int e = 0; e < 2; ++e) {
                 const int ra = a_lds_row(ln, s, e), rb = b_lds_row(ln, s, e);
                 int m = tc.m0 + ra;
-                m = m < p.M ? m : p.M - 1;
+                m = m < q.M ? m : q.M - 1;
                 long long el;
                 if (CONV) {
                     const int hw = p.cg.H * p.cg.W;
@@ -270,13 +278,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     constexpr bool FOLD_BIAS = (EPI & 1) == 0;
     auto load_bias = [&](int seq) {
         const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
+        const float* const bias_ = p.pr[CONV ? 0 : tc.g].bias;
         const f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         nb0 = nb1 = nb2 = nb3 = z;
         // (the parts of a split tail tile start from zero: gemm8p_tail_kernel adds the bias)
-        if (FOLD_BIAS && p.bias && !(tail_parks && seq >= n_full)) {
+        if (FOLD_BIAS && bias_ && !(tail_parks && seq >= n_full)) {
             const int c0 = tc.n0 + wn * 64 + 8 * fq, c1 = c0 + 32;
-            const float* b0 = p.bias + (c0 < p.n_valid ? c0 : 0);
-            const float* b1 = p.bias + (c1 < p.n_valid ? c1 : 0);
+            const float* b0 = bias_ + (c0 < p.n_valid ? c0 : 0);
+            const float* b1 = bias_ + (c1 < p.n_valid ? c1 : 0);
             nb0 = *(const f32x4_t*)b0;
             nb1 = *(const f32x4_t*)(b0 + 4);
             nb2 = *(const f32x4_t*)b1;
@@ -348,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                 if (j_next + k < U) { issue_unit(j_next + k, (LA + k) & 3); ++n_pre; }
         }
         const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
+        const Prob& q = p.pr[CONV ? 0 : tc.g];
         const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
         const bool mapped = CONV && p.om.mode == 1;
         // 0 = not a QK wave tile, 1 = K block, 2 = Q block (scalar)
@@ -396,11 +406,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                            p.om.Cout_pitch + cc;
                 return tf >= 0;
             }
-            coff = (long long)tc.b * p.sC + (long long)m * p.ldc + n;
+            coff = (long long)tc.b * q.sC + (long long)m * p.ldc + n;
             return true;
         };
-        const bf16_t* res_row = E_RES ? p.res + (long long)tc.b * p.sR + (long long)(wave_m0 + frow) * p.ldr : nullptr;
-        char* const c_row = (char*)p.C + ((long long)tc.b * p.sC + (long long)(wave_m0 + frow) * p.ldc) * (E_F32 ? 4 : 2);
+        const bf16_t* res_row = E_RES ? q.res + (long long)tc.b * q.sR + (long long)(wave_m0 + frow) * p.ldr : nullptr;
+        char* const c_row = (char*)q.C + ((long long)tc.b * q.sC + (long long)(wave_m0 + frow) * p.ldc) * (E_F32 ? 4 : 2);
         int ncol[2];
         bool ncol_ok[2];
         f32x4_t gate4[2][2];
@@ -422,12 +432,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             ncol[hsel] = n;
             if (E_RES) {
                 rb0 = rb1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    rb0 = *(const f32x4_t*)(p.bias + n);
-                    rb1 = *(const f32x4_t*)(p.bias + n + 4);
+                if (q.bias) {
+                    rb0 = *(const f32x4_t*)(q.bias + n);
+                    rb1 = *(const f32x4_t*)(q.bias + n + 4);
                 }
-                if (p.gate) {
-                    const float* gp = p.gate + (long long)tc.b * p.gate_stride + n;
+                if (q.gate) {
+                    const float* gp = q.gate + (long long)tc.b * p.gate_stride + n;
                     gate4[hsel][0] = *(const f32x4_t*)gp;
                     gate4[hsel][1] = *(const f32x4_t*)(gp + 4);
                 } else {
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             f32x4_t qw0, qw1;                                   // QK: gains of this lane's 8 channels of the head
             if (E_QK) {
                 if (qk_reg) {
-                    const float* w_ = (qk_reg == 1 ? p.qk_wk : p.qk_wq) + 32 * hsel + 8 * fq;
+                    const float* w_ = (qk_reg == 1 ? q.qk_wk : q.qk_wq) + 32 * hsel + 8 * fq;
                     qw0 = *(const f32x4_t*)w_;
                     qw1 = *(const f32x4_t*)(w_ + 4);
                 }
@@ -470,13 +480,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         const int m = wave_m0 + 16 * (f0 + f) + frow;
                         if (mapped) {
                             long long roff;
-                            out_off(m < p.M ? m : p.M - 1, n, roff);
-                            rbuf[f] = *(const u32x4_t*)(p.res + roff);
+                            out_off(m < q.M ? m : q.M - 1, n, roff);
+                            rbuf[f] = *(const u32x4_t*)(q.res + roff);
                         } else {
                             // one per-lane row pointer + a wave-uniform fragment stride: no per-fragment 64-bit
                             // offsets kept alive across the epilogue; rows past M are not read at all
                             rbuf[f] = (u32x4_t){0u, 0u, 0u, 0u};
-                            if (m < p.M) rbuf[f] = *(const u32x4_t*)(res_row + (long long)(16 * (f0 + f)) * p.ldr + n);
+                            if (m < q.M) rbuf[f] = *(const u32x4_t*)(res_row + (long long)(16 * (f0 + f)) * p.ldr + n);
                         }
                     }
                 }
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 #pragma unroll
                         for (int f = 0; f < FB; ++f) {
                             const int m = wave_m0 + 16 * (f0 + f) + frow;
-                            const float* cs_ = p.qk_rope + ((long long)(p.qk_row0 + (m < p.M ? m : p.M - 1)) * 64 + 32 * hsel + 8 * fq);
+                            const float* cs_ = p.qk_rope + ((long long)(q.qk_row0 + (m < q.M ? m : q.M - 1)) * 64 + 32 * hsel + 8 * fq);
                             qcs[f][0] = *(const f32x4_t*)cs_;
                             qcs[f][1] = *(const f32x4_t*)(cs_ + 4);
                         }
@@ -566,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     }
                     if (E_F32) {
                         const int m = wave_m0 + 16 * f + frow;
-                        if (m < p.M && ncol_ok[hsel]) {
+                        if (m < q.M && ncol_ok[hsel]) {
                             float* c = (float*)(c_row + ((long long)(16 * f) * p.ldc + n) * 4);
                             *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
                             *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
@@ -599,9 +609,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     const int m = wave_m0 + 16 * f + frow;
                     if (mapped) {
                         long long coff;
-                        const bool ok = out_off(m < p.M ? m : p.M - 1, ncol[hsel], coff) && m < p.M && ncol_ok[hsel];
-                        if (ok) *(u32x4_t*)((bf16_t*)p.C + coff) = outp[hsel][f];
-                    } else if (m < p.M && ncol_ok[hsel]) {
+                        const bool ok = out_off(m < q.M ? m : q.M - 1, ncol[hsel], coff) && m < q.M && ncol_ok[hsel];
+                        if (ok) *(u32x4_t*)((bf16_t*)q.C + coff) = outp[hsel][f];
+                    } else if (m < q.M && ncol_ok[hsel]) {
                         *(u32x4_t*)(c_row + ((long long)(16 * f) * p.ldc + ncol[hsel]) * 2) = outp[hsel][f];
                     }
                     PF_FENCE();
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(256) void gemm8p_tail_kernel(const Args p) {
     const int chunk = blockIdx.x & 31, tj = blockIdx.x >> 5;
     const int xcd = tj & 7, j = tj >> 3;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int T = tiles_m * p.batch * tiles_n;
+    const int T = (tiles_m + p.tiles2_m) * p.batch * tiles_n;
     const int nwg = p.ksplit;
     const int nslot = (nwg - xcd + 7) >> 3;
     const int cq = T >> 3, cr = T & 7;
@@ -729,12 +739,13 @@ __global__ __launch_bounds__(256) void gemm8p_tail_kernel(const Args p) {
     const TailPlan tp = tail_plan(clen, nslot, nk, p.tail_ov);
     if (tp.sp <= 1 || j >= tp.r) return;
     const TileCoord tc = tile_coord(p, cs + tp.n_full * nslot + j, tiles_m, tiles_n);
+    const Prob& pq = p.pr[tc.g];
     const int lane = threadIdx.x & 63;
     const int item = chunk * 4 + (threadIdx.x >> 6);            // (wave 0..7, row fragment 0..7, column half 0..1)
     const int w = item >> 4, f = (item >> 1) & 7, hsel = item & 1;
     const int m = tc.m0 + (w >> 2) * 128 + 16 * f + (lane & 15);
     const int n = tc.n0 + (w & 3) * 64 + 32 * hsel + 8 * (lane >> 4);
-    if (m >= p.M || n >= p.n_valid) return;
+    if (m >= pq.M || n >= p.n_valid) return;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
@@ -761,27 +772,27 @@ __global__ __launch_bounds__(256) void gemm8p_tail_kernel(const Args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] += v0[e]; v[4 + e] += v1[e]; }
     }
-    if (p.bias) {
+    if (pq.bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+        for (int e = 0; e < 8; ++e) v[e] += pq.bias[n + e];
     }
     if (n >= p.gelu_from) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
     }
-    const long long coff = (long long)tc.b * p.sC + (long long)m * p.ldc + n;
+    const long long coff = (long long)tc.b * pq.sC + (long long)m * p.ldc + n;
     if (p.flags & PF_GEMM_GATE_RES) {
         float rv[8];
-        unpack8(*(const u32x4_t*)(p.res + (long long)tc.b * p.sR + (long long)m * p.ldr + n), rv);
+        unpack8(*(const u32x4_t*)(pq.res + (long long)tc.b * pq.sR + (long long)m * p.ldr + n), rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = rv[e] + (p.gate ? p.gate[(long long)tc.b * p.gate_stride + n + e] : 1.f) * v[e];
+        for (int e = 0; e < 8; ++e) v[e] = rv[e] + (pq.gate ? pq.gate[(long long)tc.b * p.gate_stride + n + e] : 1.f) * v[e];
     }
     if (p.flags & PF_GEMM_OUT_F32) {
-        float* c = (float*)p.C + coff;
+        float* c = (float*)pq.C + coff;
         *(f32x4_t*)c = (f32x4_t){v[0], v[1], v[2], v[3]};
         *(f32x4_t*)(c + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
     } else {
-        *(u32x4_t*)((bf16_t*)p.C + coff) = pack8(v);
+        *(u32x4_t*)((bf16_t*)pq.C + coff) = pack8(v);
     }
 }
 
@@ -813,7 +824,9 @@ int launch(const Args& a_in, hipStream_t stream, void* ws, long long ws_bytes) {
     PF_SET_MAX_LDS_ONCE((gemm8p_kernel<CONV, EPI>), SMEM);
     const int ncu = cu_count();
     Args a = a_in;
-    const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.batch;
+    if (CONV) a.tiles2_m = 0;
+    a.pr[0] = Prob{a.A, a.W, a.C, a.bias, a.res, a.gate, a.sA, a.sC, a.sR, a.qk_wq, a.qk_wk, a.M, a.qk_row0};
+    const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM + a.tiles2_m) * a.batch;
     // fewer tiles than CUs: with scratch the whole chip is launched anyway and the spare workgroups take K ranges of the
     // tiles (tail_plan with no full round: every tile is a tail tile), when that plan splits at all
     const bool can_split = !CONV && g_tail_split && ws && ws_bytes >= (long long)ncu * (256 << 10) && (ncu & 7) == 0;

@@ -25,6 +25,18 @@ struct OutMap {              // where output row m / column-group g lands
     int t_shift;             // added to the output frame index; negative frames are dropped
 };
 
+// per-problem fields of a gemm8p launch.  A GROUPED launch (pf_gemm_desc.M2 > 0) walks the tiles of two problems that share N, K,
+// the leading dimensions, the batch count and the epilogue flavour -- the image and the text stream of a double block
+// (flux_block.py:816-835, 868-872: same shapes, different weights and rows) -- in ONE persistent launch: pr[1]'s tiles follow
+// pr[0]'s in the tile order.  The kernel reads them as p.pr[g] with a run-time g (one scalar load from the kernel arguments
+// per field and tile, no select).
+struct Prob {
+    const bf16_t* A; const bf16_t* W; void* C; const float* bias; const bf16_t* res; const float* gate;
+    long long sA, sC, sR;
+    const float* qk_wq; const float* qk_wk;
+    int M, qk_row0;
+};
+
 struct Args {
     const bf16_t* A; const bf16_t* W; void* C;
     const float* bias; const bf16_t* res; const float* gate;
@@ -50,6 +62,8 @@ struct Args {
     double* gn_stats;        // conv kernels of gemm256.hip: [frame][gn_C][2] (sum, sum of squares) of the OUTPUT, accumulated in
     int gn_C;                //   the epilogue for the GroupNorm that reads it (nullptr = none)
     ConvGeom cg; OutMap om;
+    Prob pr[2];              // gemm8p: [0] = the fields above (filled by its launcher), [1] = the second problem of a grouped launch
+    int tiles2_m;            //   256-row tiles per batch entry of pr[1] (0 = not grouped)
 };
 
 

@@ -9,6 +9,7 @@ Fused projections: per double block K|V|Q share one GEMM per stream; per single 
 out-projection reads `[O | mlp]` (= the reference's `cat([attn, mlp])`, flux_block.py:936) in place.
 """
 import contextlib
+import ctypes as C
 
 import torch
 
@@ -201,6 +202,8 @@ class FluxEngine(DeviceModuleAPI):
         self.overlap_text = True        # text stream of the double blocks on a side HIP stream
         self.skip_dead_rows = True      # last block: Q / MLP / attention / proj_out only for the current frame's rows
         self.fuse_qk = True             # QK-RMSNorm + RoPE inside the K|V|Q projections (pf_gemm_desc.qk_*); False = separate pass
+        self.group_text = True          # double blocks: the text stream's GEMMs ride in the image stream's persistent launches
+                                        # (pf_gemm_desc.A2 ..., round 5) wherever those run the persistent kernel; False = side stream
         self.v_rowmajor = True          # attention reads V token-major (hardware transpose read); False = pf_v_transpose + V^T image
         self._side = None
         # how the ~300 launches of the blocks + head of one forward reach the device (cmdlist.py):
@@ -331,7 +334,7 @@ class FluxEngine(DeviceModuleAPI):
             # structure, the row restriction of the last block, and the GEMM dispatch policy / split-K state in force
             # when the descriptors were recorded (pf_gemm_set_policy picks kernels at record time)
             key = (id(self), self._ws_gen, self.overlap_text, self.skip_dead_rows, self.launch_mode != "list",
-                   ops.POLICY_GEN, self.fuse_qk, self.v_rowmajor)
+                   ops.POLICY_GEN, self.fuse_qk, self.v_rowmajor, self.group_text)
             ent = getattr(plan, "_launch_list", None)
             if ent is not None and ent[0] == key:
                 break
@@ -441,6 +444,7 @@ class FluxEngine(DeviceModuleAPI):
         # scratch of the compute stream's GEMMs: 64 MiB = one 256-KiB slot per workgroup of the persistent kernel, which
         # splits the tiles that do not fill its last round along K (pf_gemm_desc.workspace)
         ws_img = self._buf("gemm_tail", 16 << 20, torch.float32)
+        lib = ops.L.load()
         main = torch.cuda.current_stream()
         side = self._side_stream() if (self.overlap_text and dbl) else None
         rec = ops.RECORDER                # recording a launch list: stream switches / joins become list entries
@@ -474,6 +478,58 @@ class FluxEngine(DeviceModuleAPI):
             # and rotated (pf_gemm_desc.qk_*); the 128 text rows get the separate pass on their own stream
             fuse = self.fuse_qk
             qk_img = dict(rope=plan.rope, wq=blk["norm_q"], wk=blk["norm_k"], d=d, eps=w.qk_eps, q_scale=qs) if fuse else None
+            # GROUPED form (round 5): every projection of the block runs ONCE for both streams -- the text rows' tiles are
+            # appended to the image rows' persistent launch (same N, K, flavour; other weights, rows, gates, gains).  Taken
+            # when all of the block's image GEMMs run the persistent kernel (pf_gemm_which == 8: from ~3 000 image rows on);
+            # shorter sequences keep the two-stream form below.  No side stream, no joins, no K-split scratch.
+            if self.group_text and fuse and all(
+                    lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8
+                    for M_, N_, K_ in ((L_img, (2 if tail else 3) * d, d), (n_act, d, d), (n_act, 4 * d, d), (n_act, d, 4 * d))):
+                nq_t = blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"]
+                nk_t = blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"]
+                if pre_only:
+                    ln(Lt, 0, mb + 7 * d, mb + 6 * d)
+                else:
+                    ln(Lt, 0, mb + 6 * d, mb + 7 * d)
+                ln(L_img, Lt * d, mb + 0, mb + d)
+                txt_kvq = dict(M=Lt, W=blk["kvq_txt"][0], bias=blk["kvq_txt"][1], wq=nq_t, wk=nk_t, row0=0)
+                if tail:          # K | V of every image row (+ the text rows' K | V), then Q of the current frame's rows only
+                    ops.gemm(xn, blk["kvq_img"][0], big, L_img, 2 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                             strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d, qk=dict(qk_img, k_col0=0, row0=Lt),
+                             second=txt_kvq)
+                    ops.gemm(xn, blk["kvq_img"][0], big, n_act, d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                             strideA=Ld, strideC=L3, a_off=r0 * d, c_off=r0 * 3 * d + 2 * d, w_off=2 * d * d, bias_off=2 * d,
+                             qk=dict(qk_img, q_col0=0, row0=r0))
+                else:
+                    ops.gemm(xn, blk["kvq_img"][0], big, L_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
+                             strideA=Ld, strideC=L3, a_off=Lt * d, c_off=Lt * 3 * d,
+                             qk=dict(qk_img, k_col0=0, q_col0=2 * d, row0=Lt), second=txt_kvq)
+                if not self.v_rowmajor:
+                    ops.v_transpose(big, vT, d, 3 * d, L3, B, H, L, Lp)
+                ops.attention(big, big, vT, big, 2 * d, 0, 2 * d, 3 * d, L3, B, H, L, Lp, Lt, plan, scale, q_prescaled=True,
+                              q_row_begin=r0 if tail else 0, v_off=d if self.v_rowmajor else None)
+                txt = not pre_only
+                ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
+                         gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld, gate_stride=nm,
+                         flags=GEMM_GATE_RES, a_off=r0 * 3 * d + 2 * d, c_off=r0 * d, r_off=r0 * d, tail_workspace=ws_img,
+                         second=dict(M=Lt, W=blk["o_txt"][0], bias=blk["o_txt"][1], a_off=2 * d, gate_off=mb + 8 * d) if txt else None)
+                ln(n_act, r0 * d, mb + 3 * d, mb + 4 * d)
+                if txt:
+                    ln(Lt, 0, mb + 9 * d, mb + 10 * d)
+                ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
+                         strideA=Ld, strideC=L4, gelu_from=0, a_off=r0 * d, c_off=mlp_base + r0 * 4 * d, tail_workspace=ws_img,
+                         second=dict(M=Lt, W=blk["ff1_txt"][0], bias=blk["ff1_txt"][1], c_off=mlp_base) if txt else None)
+                ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
+                         res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + r0 * 4 * d, c_off=r0 * d, r_off=r0 * d,
+                         tail_workspace=ws_img,
+                         second=dict(M=Lt, W=blk["ff2_txt"][0], bias=blk["ff2_txt"][1], a_off=mlp_base, gate_off=mb + 11 * d) if txt else None)
+                if debug is not None and ("hidden_d0" not in debug or "blocks" in debug):
+                    snap = hidden[:B * L * d].view(B, L, d).clone()
+                    debug.setdefault("hidden_d0", snap)
+                    if "blocks" in debug:
+                        debug["blocks"].append(snap)
+                continue
             with on_side():
                 if pre_only:          # AdaLayerNormContinuous: (scale, shift) = chunks 0, 1 of the 2d modulation
                     ln(Lt, 0, mb + 7 * d, mb + 6 * d)

@@ -40,6 +40,86 @@ from .ops import GEMM_GATE_RES, GEMM_OUT_F32
 from .sp import LocalComm, SPLayout
 
 
+class _SegmentedProgram:
+    """The blocks + head of one (unit, stage) for a communicator whose calls cannot be recorded (torch.distributed): the
+    kernels BETWEEN two collective calls are recorded into launch lists (one C call each at replay), the collectives and the
+    waits on their handles are kept as Python closures in issue order.  Replay = list, exchange, list, wait, list ... --
+    ~100 short C calls + ~100 c10d calls per forward instead of ~350 Python launches (round 5; the C-ABI communicator's
+    single list, which holds the exchanges too, is the other form)."""
+
+    def __init__(self):
+        from .cmdlist import CommandList
+        self._new = CommandList
+        self.entries = []            # ("list", CommandList) | ("call", fn, id) | ("wait", id)
+        self.cur = None
+        self.n_calls = 0
+
+    def begin(self):
+        assert ops.RECORDER is None, "launch lists do not nest"
+        self.cur = self._new()
+        ops.RECORDER = self.cur
+
+    def _cut(self):
+        """close the segment being recorded (kept if it holds anything) and open the next one"""
+        if len(self.cur):
+            self.entries.append(("list", self.cur))
+        self.cur = self._new()
+        ops.RECORDER = self.cur
+
+    def add_call(self, fn):
+        self._cut()
+        self.n_calls += 1
+        self.entries.append(("call", fn, self.n_calls))
+        return self.n_calls
+
+    def add_wait(self, idx):
+        self._cut()
+        self.entries.append(("wait", idx))
+
+    def end(self):
+        if self.cur is not None and len(self.cur):
+            self.entries.append(("list", self.cur))
+        self.cur = None
+        ops.RECORDER = None
+
+    def run(self, stream):
+        handles = {}
+        for e in self.entries:
+            if e[0] == "list":
+                e[1].run(stream)
+            elif e[0] == "call":
+                handles[e[2]] = e[1]()
+            else:
+                h = handles.pop(e[1], None)
+                if h is not None:
+                    h.wait()
+
+    def __len__(self):
+        return len(self.entries)
+
+
+class _RecordingComm:
+    """stands in for the engine's communicator while a _SegmentedProgram is being recorded: every exchange becomes a program
+    entry (issued at replay through the real communicator), every handle wait too"""
+    recordable = False
+
+    class _Handle:
+        def __init__(self, prog, idx):
+            self.prog, self.idx = prog, idx
+
+        def wait(self):
+            self.prog.add_wait(self.idx)
+
+    def __init__(self, real, prog):
+        self.real, self.prog = real, prog
+        self.rank, self.world = real.rank, real.world
+
+    def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
+        r_spl, s_spl = list(recv_splits), list(send_splits)
+        idx = self.prog.add_call(lambda: self.real.all_to_all(recv, send, r_spl, s_spl, async_op=async_op))
+        return self._Handle(self.prog, idx) if async_op else None
+
+
 class FluxEngineSP(FluxEngine):
     HEAD_MAJOR = True
 
@@ -49,6 +129,7 @@ class FluxEngineSP(FluxEngine):
         self._layouts = {}
         self.launch_mode = "list"          # "list": record + replay when the communicator allows it; "eager": never
         self.split_small = True            # a rank's small image GEMMs (128 x 128 kernel, < 128 workgroups) split K through scratch
+        self.segment_lists = True          # torch.distributed collectives: the kernels between them replay from launch lists
 
     def layout(self, plan):
         key = (plan.L, plan.Lt)
@@ -201,24 +282,31 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 7 * d, mb + 6 * d)      # AdaLayerNormContinuous: (scale, shift)
             else:
                 ln(n_txt, 0, mb + 6 * d, mb + 7 * d)
+            # the rank that owns the text rows (rank 0) runs every projection of the block for both streams: GROUPED launches
+            # (pf_gemm_desc.A2 ...: the text rows' tiles in the image rows' persistent launch; the library runs two launches
+            # where the image problem does not take the persistent kernel) -- `group_text = False`: always two launches
+            grp = self.group_text and fuse and n_img > 0 and n_txt > 0
+            nq_t = blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"]
+            nk_t = blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"]
             if n_img:
                 ops.gemm(xn, blk["kvq_img"][0], big, n_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
                          strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, tail_workspace=ws_img, split_small=self.split_small,
-                         qk=qk_of(blk["norm_q"], blk["norm_k"], lay.r0 + n_txt))
-            if n_txt:         # text rows: the added-projection gains (norm_added_q / k; the image gains where the model has none)
+                         qk=qk_of(blk["norm_q"], blk["norm_k"], lay.r0 + n_txt),
+                         second=dict(M=n_txt, W=blk["kvq_txt"][0], bias=blk["kvq_txt"][1], wq=nq_t, wk=nk_t, row0=lay.r0) if grp else None)
+            if n_txt and not grp:         # text rows: the added-projection gains (norm_added_q / k; the image gains where the model has none)
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
-                         strideA=Ld, strideC=L3, workspace=ws_txt,
-                         qk=qk_of(blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"],
-                                  blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"], lay.r0))
+                         strideA=Ld, strideC=L3, workspace=ws_txt, qk=qk_of(nq_t, nk_t, lay.r0))
             norms = (blk["norm_q"], blk["norm_k"], blk["norm_added_q"], blk["norm_added_k"])
             attend(3 * d, norms, q_row_begin=r_cur if tail else 0)
             h2 = self._exchange_out_start(lay, obuf, B, recv2)
             self._exchange_out_finish(lay, h2, B, recv2, big, 3 * d, 0)          # attention rows -> big[..., 0:d]
+            grp2 = grp and n_act > 0 and not pre_only          # the post-attention GEMMs of both streams
             if n_act > 0:
                 ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
-                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small)
-            if n_txt and not pre_only:
+                         gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small,
+                         second=dict(M=n_txt, W=blk["o_txt"][0], bias=blk["o_txt"][1], gate_off=mb + 8 * d) if grp2 else None)
+            if n_txt and not pre_only and not grp2:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, workspace=ws_txt)
@@ -227,12 +315,14 @@ class FluxEngineSP(FluxEngine):
                 ln(n_txt, 0, mb + 9 * d, mb + 10 * d)
             if n_act > 0:
                 ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
-                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d, tail_workspace=ws_img, split_small=self.split_small)
+                         strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d, tail_workspace=ws_img, split_small=self.split_small,
+                         second=dict(M=n_txt, W=blk["ff1_txt"][0], bias=blk["ff1_txt"][1], c_off=mlp_base) if grp2 else None)
                 ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                          res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + i0 * 4 * d, c_off=i0 * d,
-                         r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small)
-            if n_txt and not pre_only:
+                         r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small,
+                         second=dict(M=n_txt, W=blk["ff2_txt"][0], bias=blk["ff2_txt"][1], a_off=mlp_base, gate_off=mb + 11 * d) if grp2 else None)
+            if n_txt and not pre_only and not grp2:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
                 ops.gemm(big, blk["ff2_txt"][0], hidden, n_txt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],
@@ -290,13 +380,24 @@ class FluxEngineSP(FluxEngine):
         n_mod = plan.B * self.w.n_mod
         for _ in range(2):
             ms = self._buf("mod_fixed", n_mod, torch.float32)
-            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm), self.split_small, self.fuse_qk)
+            key = (id(self), self._ws_gen, self.skip_dead_rows, ops.POLICY_GEN, id(self.comm), self.split_small, self.fuse_qk, self.group_text)
             ent = getattr(plan, "_sp_list", None)
             if ent is not None and ent[0] == key:
                 break
-            cl = CommandList()
-            with recording(cl):
-                self._run_sp_blocks(plan, ms, st)
+            if getattr(self.comm, "recordable", False):
+                cl = CommandList()
+                with recording(cl):
+                    self._run_sp_blocks(plan, ms, st)
+            else:            # torch.distributed: launch-list segments between the collectives (_SegmentedProgram)
+                cl = _SegmentedProgram()
+                real = self.comm
+                self.comm = _RecordingComm(real, cl)
+                cl.begin()
+                try:
+                    self._run_sp_blocks(plan, ms, st)
+                finally:
+                    cl.end()
+                    self.comm = real
             if key[1] != self._ws_gen:           # a buffer was (re)allocated while recording: record again
                 st = self._sp_state(plan)
                 continue
@@ -332,8 +433,10 @@ class FluxEngineSP(FluxEngine):
         vtok = st["vtok"]
         if self.comm.world > 1:
             vtok[:B * n_cur * npad].zero_()
-        recordable = (self.launch_mode != "eager" and getattr(self.comm, "recordable", False) and debug is None
-                      and not ops.PROFILER.enabled)
+        # (the C-ABI communicator and a single rank: ONE list incl. the exchanges; torch.distributed: list segments between
+        #  the collectives -- FluxEngineSP.segment_lists = False keeps those eager, the round 3-4 behaviour)
+        recordable = (self.launch_mode != "eager" and debug is None and not ops.PROFILER.enabled
+                      and (getattr(self.comm, "recordable", False) or self.segment_lists))
         if recordable:
             self._run_sp_list(plan, mod, st)
         else:

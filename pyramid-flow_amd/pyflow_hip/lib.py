@@ -25,7 +25,11 @@ class GemmDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_longlong),
                 ("qk_rope", C.c_void_p), ("qk_wq", C.c_void_p), ("qk_wk", C.c_void_p),
                 ("qk_d", C.c_int), ("qk_q_col0", C.c_int), ("qk_k_col0", C.c_int), ("qk_row0", C.c_int),
-                ("qk_eps", C.c_float), ("qk_q_scale", C.c_float), ("qk_head_stride", C.c_int)]
+                ("qk_eps", C.c_float), ("qk_q_scale", C.c_float), ("qk_head_stride", C.c_int),
+                ("A2", C.c_void_p), ("W2", C.c_void_p), ("C2", C.c_void_p), ("bias2", C.c_void_p), ("res2", C.c_void_p),
+                ("gate2", C.c_void_p), ("M2", C.c_int),
+                ("strideA2", C.c_longlong), ("strideC2", C.c_longlong), ("strideR2", C.c_longlong),
+                ("qk_wq2", C.c_void_p), ("qk_wk2", C.c_void_p), ("qk_row0_2", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -63,7 +67,7 @@ class AttnSmallDesc(C.Structure):
                 ("bias", C.c_void_p), ("key_mask", C.c_void_p), ("causal", C.c_int), ("scale", C.c_float)]
 
 
-ABI_VERSION = 5          # PF_ABI_VERSION of include/pyflow_hip.h
+ABI_VERSION = 6          # PF_ABI_VERSION of include/pyflow_hip.h
 GEMM_GATE_RES = 1
 GEMM_OUT_F32 = 2
 GEMM_ACT_QUICK_GELU = 4

@@ -46,14 +46,18 @@ RECORDER = None      # a cmdlist.CommandList while a launch list is being record
 
 def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr=0, batch=1,
          strideA=0, strideC=0, strideR=0, gate_stride=0, gelu_from=-1, flags=0,
-         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None, tail_workspace=None, qk=None, split_small=False):
+         a_off=0, c_off=0, r_off=0, gate_off=0, w_off=0, bias_off=0, workspace=None, tail_workspace=None, qk=None, split_small=False,
+         second=None):
     """C = epi(A W^T). a_off/c_off/r_off are ELEMENT offsets into A / C / res.  workspace: fp32 scratch tensor that lets
     a skinny problem split its K range and a large one split its tail tiles (pf_gemm_desc.workspace); must not be
     shared by overlapping launches.  tail_workspace: the same, but handed over only to problems that run the persistent
     256 x 256 kernel (pf_gemm_which == 8): the compute stream's scratch, which leaves the summation order of small
     problems what it is without scratch.
     qk: dict(rope, wq, wk, d, q_col0, k_col0, row0, eps, q_scale[, head_stride]) -- QK-RMSNorm + RoPE of the K / Q column blocks of C as part
-    of this GEMM (pf_gemm_desc.qk_*: in the persistent kernel's epilogue, else by the library's separate pass)."""
+    of this GEMM (pf_gemm_desc.qk_*: in the persistent kernel's epilogue, else by the library's separate pass).
+    second: dict(M, W, bias, [A, C, res, gate default to the first problem's tensors], a_off, c_off, r_off, gate_off, w_off,
+    bias_off, strideA, strideC, strideR, [wq, wk, row0 with qk]) -- the second problem of a GROUPED launch (pf_gemm_desc.A2 ...:
+    same N, K, leading dimensions, batch, flags; the text stream of a double block beside the image stream)."""
     lib = L.load()
     esz_c = 4 if (flags & GEMM_OUT_F32) else 2
     d = GemmDesc()
@@ -79,6 +83,23 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
         d.qk_d, d.qk_q_col0, d.qk_k_col0, d.qk_row0 = qk["d"], qk.get("q_col0", -1), qk.get("k_col0", -1), qk.get("row0", 0)
         d.qk_eps, d.qk_q_scale = qk.get("eps", 1e-6), qk.get("q_scale", 1.0)
         d.qk_head_stride = qk.get("head_stride", 0)
+    flops = 2.0 * M * N * K * batch
+    if second is not None:
+        s2 = second
+        A2, C2 = s2.get("A", A), s2.get("C", Cout)
+        d.A2 = A2.data_ptr() + 2 * s2.get("a_off", 0)
+        d.W2 = s2["W"].data_ptr() + 2 * s2.get("w_off", 0)
+        d.C2 = C2.data_ptr() + esz_c * s2.get("c_off", 0)
+        d.bias2 = (s2["bias"].data_ptr() + 4 * s2.get("bias_off", 0)) if s2.get("bias") is not None else None
+        r2 = s2.get("res", res)
+        d.res2 = (r2.data_ptr() + 2 * s2.get("r_off", 0)) if r2 is not None else None
+        g2 = s2.get("gate", gate)
+        d.gate2 = (g2.data_ptr() + 4 * s2.get("gate_off", 0)) if g2 is not None else None
+        d.M2 = s2["M"]
+        d.strideA2, d.strideC2, d.strideR2 = s2.get("strideA", strideA), s2.get("strideC", strideC), s2.get("strideR", strideR)
+        if qk is not None:
+            d.qk_wq2, d.qk_wk2, d.qk_row0_2 = s2["wq"].data_ptr(), s2["wk"].data_ptr(), s2.get("row0", 0)
+        flops += 2.0 * s2["M"] * N * K * batch
     rec = RECORDER
     if rec is not None:
         check(lib.pf_cmdlist_gemm(rec.h, C.byref(d), C.c_int(rec.slot)))
@@ -90,7 +111,7 @@ def gemm(A, W, Cout, M, N, K, lda, ldw, ldc, bias=None, res=None, gate=None, ldr
         name = f"gemm8p_kernel<false, {epi}>" if bn == 8 else (f"gemm256_kernel<{bn}>" if bn > 0 else "gemm_kernel(128x128)")
     else:
         name = "gemm"
-    PROFILER.launch(name, 2.0 * M * N * K * batch, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
+    PROFILER.launch(name, flops, lambda: check(lib.pf_gemm_bf16(C.byref(d), stream())))
 
 
 POLICY_GEN = 0          # bumped by every gemm_set_policy: recorded launch lists / hipGraphs hold the kernels chosen at record time

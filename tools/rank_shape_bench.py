@@ -9,8 +9,9 @@ engine for the N = 1 row and, with batch 1, for the guidance-parallel rank of N 
 93 (unit, stage) sequences of one video, interpolates over the units, weights with the schedule (20 / 10 steps), and adds
   * the exchange time from the bytes a rank sends per forward and the xGMI figures of the task statement
     (7 links x 153 GB/s per GPU, one link per peer pair; `--link-eff` of that is assumed achievable) -- reported both as
-    fully exposed (upper bound) and with the single-stream blocks' K|V|Q exchange hidden under the MLP-branch GEMM it
-    overlaps with (flux_sp.py), and
+    fully exposed (upper bound) and with the single-stream blocks' exchanges partly hidden under the MLP-branch GEMM they
+    overlap with (flux_sp.py): the hidden fraction is the one MEASURED for an RCCL kernel beside the persistent GEMM on one
+    GPU (`--overlap-hidden`, 0.35: tools/comm_overlap_bench.py), and
   * the host time per forward of the launch-list replay (measured here, with the device idle),
   * the tile-parallel VAE decode: the measured single-GPU decode x ceil(7 / N) / 7 tile columns (vae.py: decode_tiles).
 Output: a table (per-kernel-family seconds per rank are in the JSON) + predicted frames/s and efficiency.
@@ -85,6 +86,11 @@ def main():
     ap.add_argument("--decode-s", type=float, default=6.4, help="measured single-GPU tiled decode of the 241 frames (s)")
     ap.add_argument("--link-gbs", type=float, default=153.0)
     ap.add_argument("--link-eff", type=float, default=0.8)
+    ap.add_argument("--overlap-hidden", type=float, default=0.35,
+                    help="fraction of an exchange that disappears under the GEMM queued beside it.  MEASURED on one GPU (round 5, "
+                         "tools/comm_overlap_bench.py, profiles/r05_comm_overlap_bench.log): an RCCL send / recv kernel and the persistent "
+                         "GEMM that owns every CU share the chip badly -- 0.31-0.36 of a world-1 self exchange is hidden, with or "
+                         "without reserved CUs; a blit copy of the same bytes hides 0.7-0.9 (1.0 = the round-4 assumption)")
     ap.add_argument("--latency-us", type=float, default=15.0, help="fixed cost of one grouped send/recv exchange")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -203,7 +209,8 @@ def main():
         n1 = (4 * d * 2 // 3) // 256 * 256
         t_mlp1 = 2.0 * nloc * B * n1 * d / 1.0e15 * 1e3           # MLP-branch part 1 at 1.0 PFLOP/s
         t_mlp2 = 2.0 * nloc * B * (4 * d - n1) * d / 1.0e15 * 1e3
-        hidden = 8 * (t_qkv + t_out) + 16 * (max(t_qkv - t_mlp1, 0.0) + max(t_out - t_mlp2, 0.0))
+        f = args.overlap_hidden
+        hidden = 8 * (t_qkv + t_out) + 16 * ((t_qkv - f * min(t_qkv, t_mlp1)) + (t_out - f * min(t_out, t_mlp2)))
         return full, hidden
 
     table = {}
