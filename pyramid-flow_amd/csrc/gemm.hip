@@ -304,7 +304,10 @@ static int use_gemm8p_kind(int M, int batch, int N, int K) {
     const int n256 = (N + 255) / 256 * 256;
     if ((n256 - N) * 100 >= 7 * N) return 0;
     if (tiles >= 192) return 1;
-    if (tiles >= 32 && tiles <= 128 && M >= 192 && pf_gemm8p_mid_split((int)tiles, K / 64) > 1) return 2;
+    // (round 5: where the 256-row ping-pong kernel fills the chip with 256 x 128 tiles -- a P = 8 rank's N = 1920 projections: 240
+    //  tiles -- it now runs 1.03-1.06 PFLOP/s as ONE launch and beats the K split's 0.93-1.02: profiles/r05_gemm_rank_shapes.log)
+    if (tiles >= 32 && tiles <= 128 && M >= 192 && pf_gemm256_pick((long long)M * batch, M, batch, N, 0) == 0 &&
+        pf_gemm8p_mid_split((int)tiles, K / 64) > 1) return 2;
     return 0;
 }
 static bool use_gemm8p(int M, int batch, int N, int K) { return use_gemm8p_kind(M, batch, N, K) != 0; }

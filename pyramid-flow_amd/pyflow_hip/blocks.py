@@ -107,7 +107,7 @@ class _BlockOp(DeviceModuleAPI):
         eng.w = FluxWeights(sd, cfg, self.dev, blocks_only=True)
         eng.cfg, eng._ws, eng._ctx, eng._mod_cache = cfg, {}, None, None
         eng.overlap_text, eng.skip_dead_rows, eng._side = False, False, None
-        eng.fuse_qk = eng.v_rowmajor = True
+        eng.fuse_qk = eng.v_rowmajor = eng.group_text = True
         eng.launch_mode, eng._ws_gen = "eager", 0
         eng._listed_plans = None
         self._eng = eng

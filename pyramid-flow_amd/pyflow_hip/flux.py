@@ -482,8 +482,10 @@ class FluxEngine(DeviceModuleAPI):
             # appended to the image rows' persistent launch (same N, K, flavour; other weights, rows, gates, gains).  Taken
             # when all of the block's image GEMMs run the persistent kernel (pf_gemm_which == 8: from ~3 000 image rows on);
             # shorter sequences keep the two-stream form below.  No side stream, no joins, no K-split scratch.
+            # (whole-round launches only: >= 192 tiles, what runs the persistent kernel without K-split scratch and with the QK epilogue)
             if self.group_text and fuse and all(
-                    lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8
+                    lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8 and
+                    -(-M_ // 256) * B * -(-N_ // 256) >= 192
                     for M_, N_, K_ in ((L_img, (2 if tail else 3) * d, d), (n_act, d, d), (n_act, 4 * d, d), (n_act, d, 4 * d))):
                 nq_t = blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"]
                 nk_t = blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"]

@@ -32,6 +32,8 @@ Text rows stay with the ranks that own them in the merged order (rank 0 at P <= 
 stream the text-stream weights once and cost 0.26 ms per forward when run alone -- splitting them over
 ranks would make EVERY rank stream those weights and save nothing.
 """
+import ctypes as C
+
 import torch
 
 from . import ops
@@ -221,6 +223,7 @@ class FluxEngineSP(FluxEngine):
         d = w.d
         B, Lt, L, Lp = plan.B, plan.Lt, plan.L, plan.Lp
         lay = st["lay"]
+        lib = ops.L.load()
         nloc, n_txt, n_img = lay.nloc, lay.n_txt, lay.n_img
         mh, mc = lay.my_heads, lay.my_cols
         hidden, xn, big, send1, recv1, obuf, recv2, vT, ws_txt, ws_img, vtok = (st[k] for k in (
@@ -285,28 +288,36 @@ class FluxEngineSP(FluxEngine):
             # the rank that owns the text rows (rank 0) runs every projection of the block for both streams: GROUPED launches
             # (pf_gemm_desc.A2 ...: the text rows' tiles in the image rows' persistent launch; the library runs two launches
             # where the image problem does not take the persistent kernel) -- `group_text = False`: always two launches
+            # -- per projection, and only where the image problem takes the persistent kernel: everywhere else the text rows keep
+            # their own launch with their own K-split scratch (the single-rank engine's summation order, bit for bit)
             grp = self.group_text and fuse and n_img > 0 and n_txt > 0
+
+            def groups(M_, N_, K_):
+                return grp and M_ > 0 and lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8
+            g_kvq = groups(n_img, 3 * d, d)
             nq_t = blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"]
             nk_t = blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"]
             if n_img:
                 ops.gemm(xn, blk["kvq_img"][0], big, n_img, 3 * d, d, d, d, 3 * d, bias=blk["kvq_img"][1], batch=B,
                          strideA=Ld, strideC=L3, a_off=n_txt * d, c_off=n_txt * 3 * d, tail_workspace=ws_img, split_small=self.split_small,
                          qk=qk_of(blk["norm_q"], blk["norm_k"], lay.r0 + n_txt),
-                         second=dict(M=n_txt, W=blk["kvq_txt"][0], bias=blk["kvq_txt"][1], wq=nq_t, wk=nk_t, row0=lay.r0) if grp else None)
-            if n_txt and not grp:         # text rows: the added-projection gains (norm_added_q / k; the image gains where the model has none)
+                         second=dict(M=n_txt, W=blk["kvq_txt"][0], bias=blk["kvq_txt"][1], wq=nq_t, wk=nk_t, row0=lay.r0) if g_kvq else None)
+            if n_txt and not g_kvq:         # text rows: the added-projection gains (norm_added_q / k; the image gains where the model has none)
                 ops.gemm(xn, blk["kvq_txt"][0], big, n_txt, 3 * d, d, d, d, 3 * d, bias=blk["kvq_txt"][1], batch=B,
                          strideA=Ld, strideC=L3, workspace=ws_txt, qk=qk_of(nq_t, nk_t, lay.r0))
             norms = (blk["norm_q"], blk["norm_k"], blk["norm_added_q"], blk["norm_added_k"])
             attend(3 * d, norms, q_row_begin=r_cur if tail else 0)
             h2 = self._exchange_out_start(lay, obuf, B, recv2)
             self._exchange_out_finish(lay, h2, B, recv2, big, 3 * d, 0)          # attention rows -> big[..., 0:d]
-            grp2 = grp and n_act > 0 and not pre_only          # the post-attention GEMMs of both streams
+            post = grp and n_act > 0 and not pre_only          # the post-attention GEMMs of both streams
+            g_o = post and groups(n_act, d, d)
+            g_ff = post and groups(n_act, 4 * d, d) and groups(n_act, d, 4 * d)          # (the MLP's two GEMMs: both or neither)
             if n_act > 0:
                 ops.gemm(big, blk["o_img"][0], hidden, n_act, d, d, 3 * d, d, d, bias=blk["o_img"][1], res=hidden,
                          gate=mod, gate_off=mb + 2 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=i0 * 3 * d, c_off=i0 * d, r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small,
-                         second=dict(M=n_txt, W=blk["o_txt"][0], bias=blk["o_txt"][1], gate_off=mb + 8 * d) if grp2 else None)
-            if n_txt and not pre_only and not grp2:
+                         second=dict(M=n_txt, W=blk["o_txt"][0], bias=blk["o_txt"][1], gate_off=mb + 8 * d) if g_o else None)
+            if n_txt and not pre_only and not g_o:
                 ops.gemm(big, blk["o_txt"][0], hidden, n_txt, d, d, 3 * d, d, d, bias=blk["o_txt"][1], res=hidden,
                          gate=mod, gate_off=mb + 8 * d, ldr=d, batch=B, strideA=L3, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, workspace=ws_txt)
@@ -316,13 +327,13 @@ class FluxEngineSP(FluxEngine):
             if n_act > 0:
                 ops.gemm(xn, blk["ff1_img"][0], big, n_act, 4 * d, d, d, d, 4 * d, bias=blk["ff1_img"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, a_off=i0 * d, c_off=mlp_base + i0 * 4 * d, tail_workspace=ws_img, split_small=self.split_small,
-                         second=dict(M=n_txt, W=blk["ff1_txt"][0], bias=blk["ff1_txt"][1], c_off=mlp_base) if grp2 else None)
+                         second=dict(M=n_txt, W=blk["ff1_txt"][0], bias=blk["ff1_txt"][1], c_off=mlp_base) if g_ff else None)
                 ops.gemm(big, blk["ff2_img"][0], hidden, n_act, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_img"][1],
                          res=hidden, gate=mod, gate_off=mb + 5 * d, ldr=d, batch=B, strideA=L4, strideC=Ld, strideR=Ld,
                          gate_stride=nm, flags=GEMM_GATE_RES, a_off=mlp_base + i0 * 4 * d, c_off=i0 * d,
                          r_off=i0 * d, tail_workspace=ws_img, split_small=self.split_small,
-                         second=dict(M=n_txt, W=blk["ff2_txt"][0], bias=blk["ff2_txt"][1], a_off=mlp_base, gate_off=mb + 11 * d) if grp2 else None)
-            if n_txt and not pre_only and not grp2:
+                         second=dict(M=n_txt, W=blk["ff2_txt"][0], bias=blk["ff2_txt"][1], a_off=mlp_base, gate_off=mb + 11 * d) if g_ff else None)
+            if n_txt and not pre_only and not g_ff:
                 ops.gemm(xn, blk["ff1_txt"][0], big, n_txt, 4 * d, d, d, d, 4 * d, bias=blk["ff1_txt"][1], batch=B,
                          strideA=Ld, strideC=L4, gelu_from=0, c_off=mlp_base, workspace=ws_txt)
                 ops.gemm(big, blk["ff2_txt"][0], hidden, n_txt, d, 4 * d, 4 * d, 4 * d, d, bias=blk["ff2_txt"][1],

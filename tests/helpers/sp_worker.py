@@ -55,7 +55,7 @@ def main():
     # (flux_sp._SegmentedProgram); the eager issue of the same sequence must give the same bits, also on a second replay
     assert eng.launch_mode == "list" and not getattr(eng.comm, "recordable", False)
     seg = getattr(plan, "_sp_list", None)
-    assert seg is not None and type(seg[1]).__name__ == "_SegmentedProgram" and len(seg[1]) > 20, seg
+    assert seg is not None and type(seg[1]).__name__ == "_SegmentedProgram" and len(seg[1]) > 8, (seg, len(seg[1]))
     v_again = eng.forward_tokens(plan, clips, t, pooled).clone()
     eng.launch_mode = "eager"
     v_eager = eng.forward_tokens(plan, clips, t, pooled).clone()

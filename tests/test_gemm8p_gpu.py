@@ -283,8 +283,17 @@ def test_gemm8p_tail_split_policy_switch(ws64):
     assert ops.L.load().pf_gemm_workspace_bytes(M, 1, N, K) == 64 << 20
 
 
-@pytest.mark.parametrize("M,B,N,K", [(1936, 2, 1920, 7680), (1936, 2, 1920, 9600), (946, 2, 1920, 9600), (946, 2, 1920, 1920),
-                                     (496, 2, 1920, 9600), (1210, 1, 1920, 7680)])
+def test_rank_shapes_at_p8_take_the_256_row_kernel_as_one_launch():
+    """round 5: a P = 8 rank's N = 1920 projections (2 x 1 936 rows: 240 tiles of 256 x 128) run the 256-row ping-pong kernel
+    as ONE launch (its epilogue no longer serialises its loads and stores: 1.03-1.06 PFLOP/s where the persistent kernel's
+    whole-launch K split ran 0.93-1.02, profiles/r05_gemm_rank_shapes.log); the K split keeps the shapes below"""
+    from pyflow_hip import ops
+    so = ops.L.load()
+    for K in (1920, 7680, 9600):
+        assert so.pf_gemm_which(1936, 2, 1920, K) == 128
+
+
+@pytest.mark.parametrize("M,B,N,K", [(946, 2, 1920, 9600), (946, 2, 1920, 1920), (496, 2, 1920, 9600), (1210, 1, 1920, 7680)])
 def test_gemm8p_mid_size_whole_launch_k_split(ws64, M, B, N, K):
     """a sequence-parallel rank's N = 1920 projections (P = 4 / 8: L / P rows, 32 .. 128 tiles of 256 x 256): with scratch the
     persistent kernel is launched on the whole chip and every tile's K range is split over 256 / T workgroups (tail_plan with

@@ -147,6 +147,7 @@ def test_forward_identical_with_and_without_the_fused_epilogue():
     mask[1, :96] = 1
     pooled = torch.randn(2, 768, generator=g)
     eng = FluxEngine(sd, cfg, DEV)
+    eng.group_text = False          # (the grouped double blocks need the fused epilogue: they are compared in test_gemm_grouped_gpu.py)
     plan = eng.make_plan(shapes, mask)
     eng.encode_context(enc)
     outs = {}

@@ -168,3 +168,64 @@ def test_guidance_pair_gather_over_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True, True, True), (1, True, True, True)], res
+
+
+def test_segmented_program_structure_on_cpu():
+    """flux_sp._SegmentedProgram (round 5): what the sequence-parallel engine records when its communicator's calls cannot go
+    into a launch list (torch.distributed) -- launch-list segments between the collectives, the collectives and the waits on
+    their handles as closures in issue order.  Recording launches nothing, so the structure is checkable without a GPU:
+    the library's list entries are appended from CPU tensors' addresses; replay is driven with the lists' run() stubbed."""
+    from pyflow_hip import ops
+    from pyflow_hip.flux_sp import _RecordingComm, _SegmentedProgram
+
+    class FakeHandle:
+        def __init__(self, log, i):
+            self.log, self.i = log, i
+
+        def wait(self):
+            self.log.append(("waited", self.i))
+
+    class FakeComm:
+        rank, world = 1, 3
+
+        def __init__(self):
+            self.log = []
+
+        def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
+            self.log.append(("a2a", tuple(recv_splits), tuple(send_splits), async_op))
+            return FakeHandle(self.log, len(self.log)) if async_op else None
+
+    real = FakeComm()
+    prog = _SegmentedProgram()
+    comm = _RecordingComm(real, prog)
+    assert (comm.rank, comm.world) == (1, 3) and not comm.recordable
+    a = torch.zeros(64, dtype=torch.bfloat16)
+    b = torch.zeros(64, dtype=torch.bfloat16)
+    prog.begin()
+    try:
+        assert ops.RECORDER is prog.cur
+        ops.copy_rows(a, b, 1, 64, 64, 64, 0, 0, 1)                   # segment 0: one entry
+        h1 = comm.all_to_all(b, a, [8, 8, 8], [8, 8, 8], async_op=True)      # nothing is issued while recording
+        ops.copy_rows(a, b, 1, 64, 64, 64, 0, 0, 1)                   # segment 1: work that overlaps the exchange
+        ops.copy_rows(a, b, 1, 64, 64, 64, 0, 0, 1)
+        h1.wait()
+        h2 = comm.all_to_all(b, a, [4, 4, 4], [4, 4, 4], async_op=True)      # two collectives back to back: no empty list between
+        h2.wait()
+        ops.copy_rows(a, b, 1, 64, 64, 64, 0, 0, 1)                   # segment 2
+    finally:
+        prog.end()
+    assert ops.RECORDER is None and real.log == []
+    kinds = [e[0] for e in prog.entries]
+    assert kinds == ["list", "call", "list", "wait", "call", "wait", "list"], kinds
+    assert [len(e[1]) for e in prog.entries if e[0] == "list"] == [1, 2, 1]
+    ran = []
+    for e in prog.entries:
+        if e[0] == "list":
+            e[1].run = (lambda main=None, side=None, n=len(e[1]): ran.append(("list", n)))
+    for _ in range(2):                                                # replays issue the same sequence through the real communicator
+        ran.clear()
+        real.log.clear()
+        prog.run(None)
+        assert ran == [("list", 1), ("list", 2), ("list", 1)]
+        assert [x[0] for x in real.log] == ["a2a", "waited", "a2a", "waited"]
+        assert real.log[0][1:] == ((8, 8, 8), (8, 8, 8), True) and real.log[2][1] == (4, 4, 4)

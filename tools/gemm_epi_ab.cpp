@@ -88,6 +88,12 @@ int main(int argc, char** argv) {
         {L, 2, D, 5 * D, -1, true, false, "single proj_out (residual)"},
         {3008, 2, 7 * D, D, 3 * D, false, true, "single K|V|Q|MLP at L = 3008"},
         {3008, 2, D, 5 * D, -1, true, false, "single proj_out at L = 3008"},
+        // a sequence-parallel rank's rows at P = 8 (L / 8 = 1 936): 128 tiles of 256 x 256 for the d-wide projections
+        {1936, 2, D, D, -1, true, false, "P = 8 rank: attn out (residual)"},
+        {1936, 2, D, 4 * D, -1, true, false, "P = 8 rank: MLP down (residual)"},
+        {1936, 2, D, 5 * D, -1, true, false, "P = 8 rank: proj_out (residual)"},
+        {1936, 2, 3 * D, D, -1, false, true, "P = 8 rank: K|V|Q (QK epilogue)"},
+        {1936, 2, 4 * D, D, 0, false, false, "P = 8 rank: MLP up (GELU)"},
     };
     const char* only = getenv("GEMM_AB_SHAPES");          // e.g. "0,1,3"
     hipStream_t st;
