@@ -28,6 +28,16 @@
 //     panels in phase (a stream-K cut of the tail into 32 equal pieces that straddle tile boundaries was measured 5-15 %
 //     slower than this on the K = 9600 GEMMs: panels are then fetched from L2 at 32 different K offsets).
 //     Over one video the DiT's N = 1920 / K = 7680-9600 GEMMs ran at 0.72 of a whole number of rounds.
+//   * EPILOGUE AND THE COMPILER'S WAITS (round 5).  The kernel orders its vector-memory traffic with inline-asm s_waitcnt; hipcc
+//     does not see those and guards the first use of every register a global load filled with a wait of its own.  Wherever
+//     such a use sits BEHIND the tile's stores that wait is an s_waitcnt vmcnt(0) for the whole store burst (rounds 2-4: the
+//     next tile's bias -> every epilogue drained its stores; the residual flavour's second column half -> 16 store round
+//     trips).  Rule of this file: every register a global load fills is REDEFINED (asm volatile("" : "+v"(x))) directly behind
+//     the asm drain that covers it; tests/test_kernel_isa.py checks the result in the ISA (16 stores in one run, no wait behind
+//     them, no scratch).  The two wave groups' epilogues run in the SAME barrier interval (group 0 takes the loop's last
+//     barrier first: epi_mode bit 0); waves without epilogue loads drain the DMA queue after their conversions.
+//   * GROUPED LAUNCH (round 5, pf_gemm_desc.A2 ...): the tile list may continue with the tiles of a second problem of the same
+//     N / K / flavour (the text stream of a double block); per-problem fields are read as p.pr[g] from the kernel arguments.
 // LDS: 2 K-tile buffers x (A 256 x 64 + W 256 x 64) bf16 = 128 KiB, XOR-swizzled like gemm256.hip (swizzle on the DMA
 // source address and on the ds_read_b128 address).
 #include "common.h"
