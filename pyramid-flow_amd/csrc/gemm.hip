@@ -321,7 +321,7 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 7 || force == -7) { g_halo_maps = force > 0; return 0; }
     if (force == 9 || force == -9) { pf_gemm8p_set_stagger(force > 0 ? 290 : 0); return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
-    if (force >= 1000 && force < 1064) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // measurement hook: Args::epi_mode bits
+    if (force == 1000 || force == 1001) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // measurement hook: Args::epi_mode
     if (force >= 2000 && force <= 2128) { pf_gemm8p_set_reserved_cus(force - 2000); return 0; } // CUs the persistent launches leave to communication kernels
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
         return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c, 1000 + m or 2000 + R");

@@ -354,18 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     // batches of QFB row fragments per column half (all loads of a batch before its one drain, as for the residual).
     constexpr bool E_RES = (EPI & 1) != 0, E_F32 = (EPI & 2) != 0, E_ACT = (EPI & 4) != 0, E_QK = (EPI & 8) != 0;
     static_assert(!E_QK || (!E_RES && !E_F32 && !CONV), "the QK epilogue is a form of the plain / GELU flavour");
-    // (j_next = index of the stream's next unit; returns the number of units it issued)
-    auto epilogue_tile = [&](int seq, int j_next) -> int {
-        // PRE-ISSUE (epi_mode bit 2): the two units whose ring regions died with this tile's last K-tile (its B sub 1 and A sub 1:
-        // every wave of both groups has read them) are requested NOW, in front of the tile's stores -- vmcnt retires loads and
-        // stores in issue order, so a unit issued behind the stores cannot be awaited before the store burst has drained; two
-        // more units in front of it are two more load slots of the next tile that run under the burst.
-        int n_pre = 0;
-        if (p.epi_mode & 4) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k)            // units G + LA + 1, G + LA + 2 behind the tile's last load slot G = 4 gk + 3
-                if (j_next + k < U) { issue_unit(j_next + k, (LA + k) & 3); ++n_pre; }
-        }
+    auto epilogue_tile = [&](int seq) {
         const TileCoord tc = tile_coord(p, tile_of(seq), tiles_m, tiles_n);
         const Prob& q = p.pr[CONV ? 0 : tc.g];
         const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
@@ -426,15 +415,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         f32x4_t gate4[2][2];
         f32x4_t rb0, rb1;                                       // residual flavour: bias of the current column half
         const bool more_tiles = seq + 1 < n_my;
-        // the next tile's bias: consumed after the stores are issued (acc_from_bias).  Requested AFTER the epilogue's first
-        // drain (epi_mode bit 1) so that the drain does not wait for four fresh global loads
+        // the next tile's bias: consumed after the stores are issued (acc_from_bias)
         // `early`: this wave's conversions wait for loads of their own (residual pieces, rope rows) or its stores are interleaved
         // with them (fp32 output): the vector-memory queue is drained before the first conversion.  Otherwise (plain / GELU, and
         // the V / MLP column blocks of the QK flavour) the drain comes after the conversions, directly before the first store:
         // the units requested above land under the register work.
         const bool early = E_RES || E_F32 || (E_QK && qk_reg != 0);
-        const bool bias_late = (p.epi_mode & 2) != 0 && early && !E_F32;
-        if (FOLD_BIAS && more_tiles && !bias_late) load_bias(seq + 1);
+        if (FOLD_BIAS && more_tiles) load_bias(seq + 1);
         auto load_col_params = [&](int hsel) {
             const int n_raw = wave_n0 + 32 * hsel + 8 * fq;
             ncol_ok[hsel] = n_raw < p.n_valid;
@@ -535,10 +522,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         }
                     }
                     PF_FENCE();
-                    if (hsel == 0 && f0 == 0 && FOLD_BIAS && more_tiles) {
-                        if (bias_late) load_bias(seq + 1);
-                        else if (E_F32) asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3));   // (stores interleave below)
-                    }
+                    if (hsel == 0 && f0 == 0 && FOLD_BIAS && more_tiles && E_F32)
+                        asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3));   // (this flavour's stores interleave below)
                 }
 #pragma unroll
                 for (int fi = 0; fi < FB; ++fi) {
@@ -627,7 +612,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     PF_FENCE();
                 }
         }
-        return n_pre;
     };
     // part of a split tail tile (always this workgroup's last segment): park the raw sums, lane-linear 16-byte pieces,
     // piece = accumulator index (row fragment f, column group c): slot `bid`, 32 KiB per wave
@@ -640,15 +624,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) *(f32x4v*)(pw + (f * 4 + c) * 1024) = acc[f][c];
     };
-    auto epilogue = [&](int seq, int j_next) -> int {
-        if (!CONV && tail_parks && seq >= n_full) { park(); return 0; }
-        const int n_pre = epilogue_tile(seq, j_next);
+    auto epilogue = [&](int seq) {
+        if (!CONV && tail_parks && seq >= n_full) { park(); return; }
+        epilogue_tile(seq);
         // the accumulators restart (from the next tile's bias; zero after / before a parked segment) only now:
         // re-initialising them while the packed results are still waiting for their stores would keep 128 + 64 registers
         // alive at once
         PF_FENCE();
         acc_from_bias();
-        return n_pre;
     };
 
     // ---- prologue: units 0 .. LA - 1; units 0 and 1 (A sub 0, B sub 0 of the first K-tile: what load slot 0 reads) must have
@@ -665,14 +648,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     if (wm == 1) PF_BAR();                 // group 1 runs one barrier behind group 0
 
     // ---- main loop over the K-tiles of all tiles of this workgroup
-    // load slot g reads units <= g+1 and issues unit g + LA (unless the epilogue has issued it already); then: all units
-    // <= g+2 of this wave have landed.
+    // load slot g reads units <= g+1 and issues unit g + LA; then: all units <= g+2 of this wave have landed.
     // skip_wait: load slots after an epilogue whose wait is already covered (the epilogue drained every unit issued before
-    // its stores): LA - 2 + n_pre of them; during the first n_pre (skip_wait > LA - 2) the slot's unit is already issued.
+    // its stores): LA - 2 of them.  (Requesting two more units in front of the stores, so that two more slots run under the
+    // store burst, was measured in round 5: neutral -- the stores retire within these four slots: DESIGN.md 3.)
     int skip_wait = 0;
     auto end_of_load_slot = [&](int g, const int ph) {          // g = 4 gk + ph
         if (g + LA < U) {
-            if (skip_wait <= LA - 2) issue_unit(g + LA, (ph + LA) & 3);
+            issue_unit(g + LA, (ph + LA) & 3);
             if (skip_wait > 0) --skip_wait;
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
         } else {
@@ -720,9 +703,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
             // epilogue out of the counted waits
             PF_FENCE();
-            const int n_pre = epilogue(c_tile, g + 4 + LA);
+            epilogue(c_tile);
             PF_FENCE();
-            skip_wait = LA - 2 + n_pre;
+            skip_wait = LA - 2;
             ++c_tile;
             c_kt = seg_begin(c_tile);
             c_end = seg_end(c_tile);

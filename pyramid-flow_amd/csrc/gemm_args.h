@@ -53,7 +53,7 @@ struct Args {
     int stagger;             // gemm8p: > 0 = workgroups with a tile less than the busiest of their XCD start late, by
                              //   ((slot - r) % 8) * stagger * (K / 64) cycles (1/8 steps of a tile time); 0 = all start together
     int epi_mode;            // gemm8p: bit 0 = the two wave groups run their epilogues CONCURRENTLY (group 0's after the tile's last
-                             //   barrier instead of before it); bit 1 = the next tile's bias is requested after the epilogue's drain
+                             //   barrier instead of before it; the default -- 0 = one after the other: A/B switch)
     // QK-RMSNorm + RoPE of the K / Q column blocks in the epilogue (gemm8p flavour 8; pf_gemm_desc.qk_*): qk_d = 0 -> none
     const float* qk_rope; const float* qk_wq; const float* qk_wk;
     int qk_d, qk_q0, qk_k0, qk_row0;

@@ -3,7 +3,8 @@
 //   build:  hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/gemm_epi_ab.cpp -Lpyramid-flow_amd -lpyflow_hip \
 //                 -Wl,-rpath,'$ORIGIN/../pyramid-flow_amd' -o tools/gemm_epi_ab
 //   run:    tools/gemm_epi_ab [rounds] [arm policy lists, e.g. "1000" "1003"]   (an arm = comma-separated policy values
-//           applied in order before the launch; default arms: 1000 (round-4 epilogue order) and 1003 (round 5))
+//           applied in order before the launch; default arms: 1000 (the wave groups' epilogues one after the other, as in
+//           round 4) and 1001 (concurrent: round 5's default))
 // Prints per shape: median / min / max TFLOP/s per arm and whether the arms' outputs are bit-identical (64-bit checksums).
 #include <hip/hip_runtime.h>
 
@@ -77,7 +78,7 @@ int main(int argc, char** argv) {
         arm_names.push_back(argv[i]);
         free(dup);
     }
-    if (arms.empty()) { arms = {{1000}, {1003}}; arm_names = {"1000", "1003"}; }
+    if (arms.empty()) { arms = {{1000}, {1001}}; arm_names = {"1000", "1001"}; }
     const int D = 1920, L = 15488;
     const Shape shapes[] = {
         {L, 2, 3 * D, D, -1, false, true, "double K|V|Q (QK epilogue)"},
