@@ -1,0 +1,122 @@
+"""Kernel ROUTING of pf_gemm_bf16 / pf_conv3d_bf16 without a GPU: the decisions are host code behind the C ABI
+(pf_gemm_which, pf_gemm_which_desc, pf_gemm_workspace_bytes, pf_conv3d_which, pf_gemm_workgroups), so the CPU tier can pin
+them -- what the round-4 advisor found wrong (a 32..128-tile conv routed to the persistent kernel on a fraction of the chip;
+pf_gemm_which reporting 8 for problems pf_gemm_bf16 does not run there) and the round-5 rules (grouped launches only where the
+persistent kernel serves the first problem; a P = 8 rank's N = 1920 projections on the 256-row kernel; reserved CUs)."""
+import ctypes as C
+
+import pytest
+
+
+@pytest.fixture
+def so():
+    from pyflow_hip import lib
+    s = lib.load()
+    s.pf_gemm_workspace_bytes.restype = C.c_longlong
+    s.pf_gemm_set_policy(0)
+    s.pf_gemm_set_policy(2000)
+    yield s
+    s.pf_gemm_set_policy(0)
+    s.pf_gemm_set_policy(2000)
+
+
+def _desc(M, B, N, K, ws_bytes=0, qk=False, flags=0, gelu_from=-1, M2=0):
+    from pyflow_hip.lib import GemmDesc
+    d = GemmDesc()
+    d.A = d.W = d.C = 0x1000                    # never dereferenced by the routing functions
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.ldr, d.batch = M, N, K, K, K, N, N, B
+    d.gelu_from, d.flags = gelu_from, flags
+    if ws_bytes:
+        d.workspace, d.workspace_bytes = 0x2000, ws_bytes
+    if qk:
+        d.qk_rope = d.qk_wq = d.qk_wk = 0x3000
+        d.qk_d, d.qk_q_col0, d.qk_k_col0 = 1920, 3840, 0
+    if M2:
+        d.A2 = d.W2 = d.C2 = 0x4000
+        d.M2 = M2
+    return d
+
+
+def test_gemm_routing_of_the_dit_shapes(so):
+    d = 1920
+    # the headline sequence: every image projection is a whole-round launch of the persistent kernel
+    for N, K in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d), (7 * d, d), (d, 5 * d)):
+        assert so.pf_gemm_which(15488, 2, N, K) == 8
+        assert so.pf_gemm_which_desc(C.byref(_desc(15488, 2, N, K))) == 8
+    # scratch pays for the N = 1920 launches (tail split), not for launches that fill their last round
+    assert so.pf_gemm_workspace_bytes(15488, 2, d, 5 * d) == 64 << 20
+    # the 128 text rows: the 128 x 128 kernel, with a K split when the caller brings scratch
+    assert so.pf_gemm_which(128, 2, 3 * d, d) == 0 and so.pf_gemm_workspace_bytes(128, 2, d, 4 * d) > 0
+    # round 5: a P = 8 rank's rows (2 x 1 936): the wide projections stay on the persistent kernel, the d-wide ones run the
+    # 256-row kernel with 256 x 128 tiles as ONE launch and ask for no scratch
+    assert so.pf_gemm_which(1936, 2, 3 * d, d) == 8 and so.pf_gemm_which(1936, 2, 4 * d, d) == 8
+    for K in (d, 4 * d, 5 * d):
+        assert so.pf_gemm_which(1936, 2, d, K) == 128 and so.pf_gemm_workspace_bytes(1936, 2, d, K) == 0
+
+
+def test_which_desc_mirrors_the_launch_decision(so):
+    d, ws = 1920, 64 << 20
+    # a mid-size problem the 256-row kernel cannot fill the chip with (P = 16 rows): the persistent kernel ONLY with enough scratch
+    # and without a QK epilogue (the split's second launch applies none)
+    M, B = 946, 2
+    assert so.pf_gemm_which(M, B, d, 5 * d) == 8
+    assert so.pf_gemm_which_desc(C.byref(_desc(M, B, d, 5 * d, ws_bytes=ws))) == 8
+    assert so.pf_gemm_which_desc(C.byref(_desc(M, B, d, 5 * d))) != 8
+    assert so.pf_gemm_which_desc(C.byref(_desc(M, B, d, 5 * d, ws_bytes=1 << 20))) != 8
+    # a flavour without an instantiation (residual + GELU) goes to the older kernels even at full size
+    from pyflow_hip.lib import GEMM_GATE_RES
+    assert so.pf_gemm_which_desc(C.byref(_desc(15488, 2, 4 * d, d, flags=GEMM_GATE_RES, gelu_from=0))) != 8
+    # whole-round launches take the QK epilogue; forcing / forbidding the persistent kernel is honoured
+    assert so.pf_gemm_which_desc(C.byref(_desc(15488, 2, 3 * d, d, qk=True))) == 8
+    so.pf_gemm_set_policy(-8)
+    assert so.pf_gemm_which_desc(C.byref(_desc(15488, 2, 3 * d, d, qk=True))) != 8
+    so.pf_gemm_set_policy(8)
+    assert so.pf_gemm_which_desc(C.byref(_desc(300, 1, 256, 64))) == 8
+    so.pf_gemm_set_policy(0)
+    assert so.pf_gemm_which_desc(None) == -100
+
+
+def test_reserved_cus_policy(so):
+    assert so.pf_gemm_workgroups() == 256 or so.pf_gemm_workgroups() % 8 == 0
+    full = so.pf_gemm_workgroups()
+    for R, want in ((8, full - 8), (13, full - 16), (32, full - 32), (0, full)):
+        assert so.pf_gemm_set_policy(2000 + R) == 0
+        assert so.pf_gemm_workgroups() == want
+    so.pf_gemm_set_policy(2000 + 16)
+    so.pf_gemm_set_policy(0)                      # the kernel-selection reset leaves the reservation alone (its owner clears it)
+    assert so.pf_gemm_workgroups() == full - 16
+    so.pf_gemm_set_policy(2000)
+    assert so.pf_gemm_set_policy(2129) != 0       # out of range
+
+
+def _conv_desc(T, H, W, Cin, N, k=3):
+    from pyflow_hip.lib import ConvDesc
+    d = ConvDesc()
+    d.X = d.W = d.Y = d.bias = 0x1000
+    d.T, d.H, d.W_ = T, H, W
+    d.in_sh = d.in_sw = d.in_st = 1
+    d.Hp, d.Wp, d.Cin = H + 2, W + 2, Cin
+    d.kt = d.kh = d.kw = k
+    d.N, d.n_valid = N, N
+    d.st = d.sh = d.sw = 1
+    d.Cg, d.Hop, d.Wop, d.Cout_pitch = N, H + 2, W + 2, N
+    d.out_scale = 1.0
+    return d
+
+
+def test_conv_routing(so):
+    # the decoder's full-resolution resnet convs: the LDS-halo direct convolution
+    assert so.pf_conv3d_which(C.byref(_conv_desc(8, 256, 256, 128, 128))) == -2
+    # round-4 advisor finding: a 32..128-tile conv (512 -> 512 at 64 x 64, two frames: 32 x 2 tiles) must NOT take the persistent
+    # kernel (a conv never splits K: it would run on a fraction of the chip) -- the 256-row kernels, which also fuse the statistics
+    so.pf_gemm_set_policy(-5)                     # (without the halo kernel: the implicit-GEMM routes)
+    for T in (2, 3, 4):                           # 64 / 96 / 128 tiles of 256 x 256
+        r = so.pf_conv3d_which(C.byref(_conv_desc(T, 64, 64, 512, 512)))
+        assert r in (0, 128, 192, 256), (T, r)    # the 128 x 128 kernel (256 workgroups at T = 2) or a 256-row kernel, never 8
+    # whole-round launches do take it
+    assert so.pf_conv3d_which(C.byref(_conv_desc(8, 128, 128, 256, 256))) == 8
+    so.pf_gemm_set_policy(5)
+    # conv_out (3 filters): the narrow-N kernel
+    d = _conv_desc(8, 256, 256, 128, 128)
+    d.n_valid, d.Cg, d.Cout_pitch = 3, 8, 8       # three real filters into the 8-channel image buffer
+    assert so.pf_conv3d_which(C.byref(d)) == -1
