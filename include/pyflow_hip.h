@@ -123,6 +123,8 @@ long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
  * that the chip's 256 epilogues do not store in one burst; timing only, same bits; off by default); 400 + c (c = 0..199) = measurement hook: the
  * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0); 1000 + m = measurement hook of the persistent
  * kernel's epilogue schedule (m = 1: the two wave groups' epilogues run concurrently -- the default; m = 0: one after the other);
+ * 1202 / 1203 = measurement hook: the 128 x 128 kernel always with two LDS stages / with three for launches of at most one
+ * workgroup per CU (the default); 1204 / 1205 = the K split of skinny problems capped at 256 workgroups (the default) / not;
  * 2000 + R (R = 0 .. 128, rounded up to a multiple of 8) = the persistent kernel launches CUs - R workgroups and leaves R CUs
  * (R / 8 per XCD) to kernels that must run BESIDE it -- the RCCL send / recv kernels of a sequence-parallel exchange
  * (trainer_misc/communicate.py:7-26): a gemm8p workgroup owns its CU whole, so without a reservation an exchange in flight

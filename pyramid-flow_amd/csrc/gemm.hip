@@ -11,6 +11,12 @@
 // bank-conflict-free XOR swizzle is applied on the per-lane SOURCE address and again on the
 // ds_read_b128 address (same involution).  Double-buffered, ONE barrier per K-step: the loads
 // of tile k+1 are issued right after the barrier that publishes tile k and fly under its MFMAs.
+// Round 5: launches of at most one workgroup per CU (the skinny problems this kernel still serves: the
+// text rows of short sequences, a sequence-parallel rank's small shapes, the prompt encoders) run a
+// THREE-stage ring instead (NSTAGE = 3, 96 KiB): tile k+2 is requested behind the barrier of tile k,
+// so a K-step costs half a memory latency instead of a whole one (one K-tile is 512 MFMA cycles, a
+// DMA round trip 1-2 k cycles: such launches are chains of latencies, not of MFMAs).  Larger grids keep
+// two stages and two workgroups per CU, which hide the same latency across workgroups.
 // Epilogue: accumulators are staged through LDS as fp32, then every thread streams whole
 // 16-byte bf16 pieces (bias / GELU-tanh / gate*x+residual applied in fp32) -> coalesced stores.
 #include "common.h"
@@ -25,9 +31,10 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + W
 constexpr int SMEM_BYTES = 2 * BUF_BYTES;        // double buffered = 64 KiB (= fp32 128x128 epilogue stage)
+constexpr int SMEM_BYTES3 = 3 * BUF_BYTES;       // three stages = 96 KiB (one workgroup per CU)
 
-template <bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
+template <bool CONV, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,11 +110,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
 
     const int kt_begin = (int)((long long)nk * ks_id / ksplit), kt_end = (int)((long long)nk * (ks_id + 1) / ksplit);
     issue(kt_begin, 0);
+    if (NSTAGE == 3 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
+    int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
+        if (NSTAGE == 3) {
+            // tile kt has landed (this wave's 8 pieces of tile kt + 1 may still be in flight); behind the barrier every wave is
+            // done with tile kt - 1, whose buffer takes tile kt + 2
+            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < kt_end) issue(kt + 2, buf >= 1 ? buf - 1 : 2);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
+        }
         const char* sa = smem + buf * BUF_BYTES;
         const char* sw = sa + TILE_BYTES;
 #pragma unroll
@@ -125,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Args p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
         }
+        buf = NSTAGE == 3 ? (buf == 2 ? 0 : buf + 1) : buf ^ 1;
     }
     // ---- epilogue: stage fp32 accumulators in LDS (128x128 fp32 = 64 KiB) ----
     __builtin_amdgcn_s_barrier();
@@ -288,6 +306,8 @@ static bool g_halo_enabled = true;           // pf_gemm_set_policy(-5) / (5): ne
 static bool g_halo_maps = true;              // pf_gemm_set_policy(-7) / (7): the upsamplers' shuffled output maps stay with the implicit GEMM / take the halo kernel
 static bool g_halo_wide = true;              // pf_gemm_set_policy(-6) / (6): only the N = 128 layers / also the 256- and 512-filter layers
 static bool g_splitk_enabled = true;          // pf_gemm_set_policy(-2) / (2): never / again split K for skinny problems
+static bool g_stage3_enabled = true;          // pf_gemm_set_policy(1202) / (1203): the 128 x 128 kernel always with two stages / three for grids <= 256
+static bool g_split_cap = true;               // pf_gemm_set_policy(1204) / (1205): the K split capped at one workgroup per CU (so that it runs three stages) / not
 static const bool g_gemm8p_auto = true;       // measured ahead of gemm256 on every large DiT shape (profiles/r02_gemm_ab*.log)
 // 1 = a launch of >= 192 tiles (whole rounds + tail), 2 = a MID-SIZE launch (32 .. 128 tiles, e.g. a sequence-parallel rank's
 // N = 1920 projections at P = 4 / 8: flux_block.py:868-872, 914-942 on L / P rows) that runs the persistent kernel on the
@@ -322,9 +342,11 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 9 || force == -9) { pf_gemm8p_set_stagger(force > 0 ? 290 : 0); return 0; }
     if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
     if (force == 1000 || force == 1001) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // measurement hook: Args::epi_mode
+    if (force == 1202 || force == 1203) { g_stage3_enabled = force == 1203; return 0; }         // measurement hook: stages of the 128 x 128 kernel
+    if (force == 1204 || force == 1205) { g_split_cap = force == 1204; return 0; }              // measurement hook: K split capped at 256 workgroups
     if (force >= 2000 && force <= 2128) { pf_gemm8p_set_reserved_cus(force - 2000); return 0; } // CUs the persistent launches leave to communication kernels
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c, 1000 + m or 2000 + R");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c, 1000 / 1001, 1202 .. 1205 or 2000 + R");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;
@@ -332,6 +354,8 @@ extern "C" int pf_gemm_set_policy(int force) {
     pf_gemm8p_set_tail_overhead(4);          // the measurement hook (400 + c) does not outlive a reset to automatic
     pf_gemm8p_set_stagger(0);
     pf_gemm8p_set_epi_mode(1);
+    g_stage3_enabled = true;
+    g_split_cap = true;
     return 0;
 }
 // Scratch that pays for this problem (pf_gemm_desc.workspace): 0 = none is used.  Large problems on the persistent 256 x 256
@@ -471,7 +495,11 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
     // K-tiles; a second launch sums the parts in split order and applies the epilogue.
     const int nk = d->K / BK;
     if (d->workspace && grid < 128 && nk >= 8 && g_splitk_enabled) {
+        // ~256 workgroups -- and, since round 5, AT MOST 256: one per CU, which run the three-stage ring (a split of 90 tiles
+        // into 3 x 90 = 270 two-stage workgroups ran 259 TFLOP/s where 2 x 90 three-stage ones run 290: profiles/
+        // r05_gemm128_three_stage_ab.log)
         int ks = (256 + grid - 1) / grid;
+        if (g_split_cap && ks > 1 && grid * ks > 256) ks = 256 / grid;
         ks = ks < nk / 4 ? ks : nk / 4;
         const long long per_split = (long long)d->batch * d->M * d->N * 4;
         if (per_split * ks > d->workspace_bytes) ks = (int)(d->workspace_bytes / per_split);
@@ -481,8 +509,13 @@ extern "C" int pf_gemm_bf16(const pf_gemm_desc* d, hipStream_t stream) {
             grid *= ks;
         }
     }
-    PF_SET_MAX_LDS_ONCE((gemm_kernel<false>), SMEM_BYTES);
-    hipLaunchKernelGGL(gemm_kernel<false>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+    if (grid <= 256 && g_stage3_enabled) {          // at most one workgroup per CU: the three-stage ring (see the file header)
+        PF_SET_MAX_LDS_ONCE((gemm_kernel<false, 3>), SMEM_BYTES3);
+        hipLaunchKernelGGL((gemm_kernel<false, 3>), dim3(grid), dim3(256), SMEM_BYTES3, stream, a);
+    } else {
+        PF_SET_MAX_LDS_ONCE((gemm_kernel<false, 2>), SMEM_BYTES);
+        hipLaunchKernelGGL((gemm_kernel<false, 2>), dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+    }
     if (a.ksplit > 1) {
         const long long total = (long long)d->batch * d->M * (d->N / 8);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
@@ -567,8 +600,13 @@ extern "C" int pf_conv3d_bf16(const pf_conv_desc* d, hipStream_t stream) {
         pf_gemm256_launch(a, route, true, stream);
     } else {
         const int grid = (a.N / BN) * ((a.M + BM - 1) / BM);
-        PF_SET_MAX_LDS_ONCE((gemm_kernel<true>), SMEM_BYTES);
-        hipLaunchKernelGGL(gemm_kernel<true>, dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+        if (grid <= 256 && g_stage3_enabled) {
+            PF_SET_MAX_LDS_ONCE((gemm_kernel<true, 3>), SMEM_BYTES3);
+            hipLaunchKernelGGL((gemm_kernel<true, 3>), dim3(grid), dim3(256), SMEM_BYTES3, stream, a);
+        } else {
+            PF_SET_MAX_LDS_ONCE((gemm_kernel<true, 2>), SMEM_BYTES);
+            hipLaunchKernelGGL((gemm_kernel<true, 2>), dim3(grid), dim3(256), SMEM_BYTES, stream, a);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(hipGetErrorString(e));

@@ -95,6 +95,12 @@ int main(int argc, char** argv) {
         {1936, 2, D, 5 * D, -1, true, false, "P = 8 rank: proj_out (residual)"},
         {1936, 2, 3 * D, D, -1, false, true, "P = 8 rank: K|V|Q (QK epilogue)"},
         {1936, 2, 4 * D, D, 0, false, false, "P = 8 rank: MLP up (GELU)"},
+        // the 128 text rows of a double block where they are not grouped (short sequences): the 128 x 128 kernel, K split with scratch
+        {128, 2, 3 * D, D, -1, false, false, "text K|V|Q (128 rows)"},
+        {128, 2, 4 * D, D, 0, false, false, "text MLP up (128 rows, GELU)"},
+        {128, 2, D, 4 * D, -1, true, false, "text MLP down (128 rows, residual)"},
+        {368, 2, D, 5 * D, -1, true, false, "proj_out at L = 368 (unit 0, stage 0)"},
+        {608, 2, 7 * D, D, 3 * D, false, false, "K|V|Q|MLP at L = 608"},
     };
     const char* only = getenv("GEMM_AB_SHAPES");          // e.g. "0,1,3"
     hipStream_t st;
