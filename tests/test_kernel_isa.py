@@ -91,3 +91,27 @@ def test_halo_conv_epilogue_loads_before_stores(tmp_path):
         assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta), name
         runs, _ = _store_runs(body)
         assert runs and all(r % 16 == 0 for r in runs), (name, runs)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src, marker, n_min", [("gemm.hip", "gemm_kernel", 4), ("gemm256.hip", "gemm256_kernel", 6),
+                                                 ("attention.hip", "attn", 8)])
+def test_no_scratch_in_the_other_kernels_with_counted_waits(tmp_path, src, marker, n_min):
+    """the 128 x 128 kernel's three-stage ring (vmcnt(8)), the 256-row ping-pong kernel and the attention kernels count their
+    LDS-DMA pieces too: a spill would be a vector-memory operation those counts do not know about"""
+    ks = {k: v for k, v in _isa(src, tmp_path).items() if marker in k}
+    assert len(ks) >= n_min, sorted(ks)
+    for name, (body, meta) in ks.items():
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta), f"{name}: scratch"
+        assert "scratch_" not in body, name
+    if src == "gemm.hip":
+        # the three-stage main loop: its only vector-memory waits are the two the source writes (the counted one, and the full
+        # drain of the last K-step) -- the compiler adds none in front of the LDS reads
+        for name, (body, _) in ks.items():
+            if "ELi3EE" not in name:
+                continue
+            lines = [ln.split(";")[0].strip() for ln in body.splitlines()]
+            first = next(i for i, t in enumerate(lines) if t.startswith("s_waitcnt vmcnt(8)"))
+            last_mfma = max(i for i, t in enumerate(lines) if t.startswith("v_mfma"))
+            between = [t for t in lines[first + 1:last_mfma] if t.startswith("s_waitcnt") and "vmcnt" in t]
+            assert between == [], (name, between)
