@@ -29,14 +29,27 @@ def exchange_unique_id(rank, world, path=None):
         return bytes(buf)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        t = torch.zeros(128, dtype=torch.uint8)
+        # 128 id bytes + one "rank 0 has an id" byte: when rank 0 cannot create the id (no librccl, ...) the other ranks are
+        # already waiting in this broadcast -- they are told, and EVERY rank raises, instead of rank 0 raising alone and the
+        # rest hanging until the process group's timeout
+        t = torch.zeros(129, dtype=torch.uint8)
+        err = None
         if rank == 0:
-            check(lib.pf_comm_unique_id(buf))
-            t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+            try:
+                check(lib.pf_comm_unique_id(buf))
+                t[:128] = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8)
+                t[128] = 1
+            except Exception as e:          # noqa: BLE001
+                err = e
         if dist.get_backend() == "nccl":
             t = t.cuda()
         dist.broadcast(t, 0)
-        return bytes(t.cpu().numpy().tobytes())
+        t = t.cpu()
+        if err is not None:
+            raise err
+        if int(t[128]) != 1:
+            raise RuntimeError("exchange_unique_id: rank 0 could not create an RCCL unique id")
+        return bytes(t[:128].numpy().tobytes())
     assert path is not None, "no torch.distributed group: pass a file path every rank can read"
     if rank == 0:
         check(lib.pf_comm_unique_id(buf))

@@ -229,3 +229,52 @@ def test_segmented_program_structure_on_cpu():
         assert ran == [("list", 1), ("list", 2), ("list", 1)]
         assert [x[0] for x in real.log] == ["a2a", "waited", "a2a", "waited"]
         assert real.log[0][1:] == ((8, 8, 8), (8, 8, 8), True) and real.log[2][1] == (4, 4, 4)
+
+
+def _uid_worker(rank, world, port, q, fail):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyflow_hip import comm_native
+    from pyflow_hip import lib as L
+    if fail and rank == 0:        # rank 0 cannot create the id (what a missing librccl gives): the library call is made to fail
+        lib = L.load()
+
+        class _Failing:
+            def __getattr__(self, name):
+                return getattr(lib, name)
+
+            @staticmethod
+            def pf_comm_unique_id(buf):
+                return 1
+        comm_native.L = type("_L", (), {"load": staticmethod(lambda: _Failing())})
+    try:
+        uid = comm_native.exchange_unique_id(rank, world)
+        q.put((rank, "ok", uid))
+    except Exception as e:              # noqa: BLE001
+        q.put((rank, "raised", type(e).__name__))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_unique_id_exchange_over_gloo(fail):
+    """comm_native.exchange_unique_id (the one use of torch.distributed by the C-ABI communicator): every rank ends with
+    rank 0's 128 bytes -- and when rank 0 cannot create an id, EVERY rank raises (bench.py then agrees on the torch.distributed
+    fallback) instead of the others waiting in the broadcast for the process group's timeout"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uid_worker, args=(r, 2, port, q, fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    if fail:
+        assert [(r, what) for r, what, _ in res] == [(0, "raised"), (1, "raised")], res
+    else:
+        assert [what for _, what, _ in res] == ["ok", "ok"] and res[0][2] == res[1][2] and len(res[0][2]) == 128, res
+        assert any(res[0][2])
