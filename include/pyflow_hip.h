@@ -118,18 +118,16 @@ long long pf_gemm_workspace_bytes(int M, int batch, int N, int K);
  * the narrow-N conv kernel (3x3x3 convs with <= 8 output channels: the decoder's conv_out); -4 / 4 = never / again
  * split the tail tiles of gemm8p problems that bring a workspace (also: the whole-launch K split of 32 .. 128-tile problems);
  * -5 / 5 = never / again the LDS-halo direct conv; -6 / 6 = halo conv only for N = 128 / also for wider layers; -7 / 7 = the
- * upsamplers' output maps stay with the implicit GEMM / take the halo kernel; 9 / -9 = desynchronised start of the persistent
- * kernel's workgroups on / off (workgroups with a tile less than the busiest of their XCD wait out a fraction of a tile time, so
- * that the chip's 256 epilogues do not store in one burst; timing only, same bits; off by default); 400 + c (c = 0..199) = measurement hook: the
- * split's assumed fixed cost in K-tile periods (default 4; reset by force = 0); 1000 + m = measurement hook of the persistent
- * kernel's epilogue schedule (m = 1: the two wave groups' epilogues run concurrently -- the default; m = 0: one after the other);
- * 1202 / 1203 = measurement hook: the 128 x 128 kernel always with two LDS stages / with three for launches of at most one
- * workgroup per CU (the default); 1204 / 1205 = the K split of skinny problems capped at 256 workgroups (the default) / not;
+ * upsamplers' output maps stay with the implicit GEMM / take the halo kernel;
  * 2000 + R (R = 0 .. 128, rounded up to a multiple of 8) = the persistent kernel launches CUs - R workgroups and leaves R CUs
  * (R / 8 per XCD) to kernels that must run BESIDE it -- the RCCL send / recv kernels of a sequence-parallel exchange
  * (trainer_misc/communicate.py:7-26): a gemm8p workgroup owns its CU whole, so without a reservation an exchange in flight
  * delays the launch by its own duration and an exchange queued behind the launch waits for its end
- * (profiles/r05_comm_overlap_bench.log).  NOT reset by force = 0: the owner of the communicator sets and clears it.  Default 0. */
+ * (profiles/r05_comm_overlap_bench.log).  NOT reset by force = 0: the owner of the communicator sets and clears it.  Default 0.
+ * A reservation that would leave the persistent kernel fewer than 64 CUs is an error (nothing changes).
+ * Measurement-only switches (desynchronised start, the tail split's cost constant, the epilogue schedule, the 128 x 128
+ * kernel's stage count / split cap) are NOT part of this library: they exist only in the lab build
+ * (`make -C pyramid-flow_amd/csrc lab` -> libpyflow_hip_lab.so, -DPF_LAB_HOOKS), which tools/ and lab/ load explicitly. */
 int pf_gemm_set_policy(int force);
 /* workgroups of a persistent-kernel launch under the current reservation (CUs - R) */
 int pf_gemm_workgroups(void);

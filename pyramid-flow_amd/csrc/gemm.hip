@@ -287,7 +287,7 @@ void pf_gemm8p_set_tail_split(bool on);
 void pf_gemm8p_set_tail_overhead(int k_tiles);
 void pf_gemm8p_set_stagger(int cycles);
 void pf_gemm8p_set_epi_mode(int mode);
-void pf_gemm8p_set_reserved_cus(int n);
+int pf_gemm8p_set_reserved_cus(int n);
 int pf_gemm8p_workgroups();
 long long pf_gemm8p_workspace_bytes();
 bool pf_gemm8p_supports(const pfgemm::Args& a, bool conv);
@@ -339,14 +339,19 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 5 || force == -5) { g_halo_enabled = force > 0; return 0; }
     if (force == 6 || force == -6) { g_halo_wide = force > 0; return 0; }
     if (force == 7 || force == -7) { g_halo_maps = force > 0; return 0; }
+#ifdef PF_LAB_HOOKS      // measurement-only switches: compiled into libpyflow_hip_lab.so (`make lab`), absent from the shipping library
     if (force == 9 || force == -9) { pf_gemm8p_set_stagger(force > 0 ? 290 : 0); return 0; }
-    if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // measurement hook: tail_plan's fixed cost
-    if (force == 1000 || force == 1001) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // measurement hook: Args::epi_mode
-    if (force == 1202 || force == 1203) { g_stage3_enabled = force == 1203; return 0; }         // measurement hook: stages of the 128 x 128 kernel
-    if (force == 1204 || force == 1205) { g_split_cap = force == 1204; return 0; }              // measurement hook: K split capped at 256 workgroups
-    if (force >= 2000 && force <= 2128) { pf_gemm8p_set_reserved_cus(force - 2000); return 0; } // CUs the persistent launches leave to communication kernels
+    if (force >= 400 && force < 600) { pf_gemm8p_set_tail_overhead(force - 400); return 0; }   // tail_plan's fixed cost
+    if (force == 1000 || force == 1001) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // Args::epi_mode
+    if (force == 1202 || force == 1203) { g_stage3_enabled = force == 1203; return 0; }         // stages of the 128 x 128 kernel
+    if (force == 1204 || force == 1205) { g_split_cap = force == 1204; return 0; }              // K split capped at 256 workgroups
+#endif
+    if (force >= 2000 && force <= 2128) {    // CUs the persistent launches leave to communication kernels
+        if (pf_gemm8p_set_reserved_cus(force - 2000)) return set_err("pf_gemm_set_policy: the reservation leaves fewer than 64 CUs to the persistent kernel");
+        return 0;
+    }
     if (force != 0 && force != -1 && force != 128 && force != 192 && force != 256)
-        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-9, 128, 192, 256, 400 + c, 1000 / 1001, 1202 .. 1205 or 2000 + R");
+        return set_err("pf_gemm_set_policy: force must be 0, -1, +-2 .. +-8, 128, 192, 256 or 2000 + R");
     g_gemm256_force = force;
     g_gemm8p_mode = 0;
     g_splitk_enabled = true;

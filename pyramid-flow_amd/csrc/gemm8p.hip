@@ -804,8 +804,7 @@ static int cu_count() {
         hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (g_num_cu <= 0) g_num_cu = 256;
     }
-    const int n = g_num_cu - g_reserve_cu;
-    return n >= 64 ? n : g_num_cu;
+    return g_num_cu - g_reserve_cu;          // pf_gemm8p_set_reserved_cus refuses reservations that leave < 64 CUs
 }
 bool g_tail_split = true;                  // pf_gemm_set_policy(-4) / (4): never / again split the tail tiles along K
 int g_tail_ov = 4;                         // fixed cost of a split in K-tile periods (tail_plan; pf_gemm_set_policy(400 + ov))
@@ -874,7 +873,13 @@ void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }
 void pf_gemm8p_set_tail_overhead(int k_tiles) { g_tail_ov = k_tiles; }
 void pf_gemm8p_set_stagger(int cycles) { g_stagger = cycles; }
 void pf_gemm8p_set_epi_mode(int mode) { g_epi_mode = mode; }
-void pf_gemm8p_set_reserved_cus(int n) { g_reserve_cu = n > 0 ? (n + 7) / 8 * 8 : 0; }
+int pf_gemm8p_set_reserved_cus(int n) {
+    const int r = n > 0 ? (n + 7) / 8 * 8 : 0;
+    g_reserve_cu = 0;
+    if (cu_count() - r < 64) return 1;          // cannot be honoured: an error, not a silently ignored request
+    g_reserve_cu = r;
+    return 0;
+}
 int pf_gemm8p_workgroups() { return cu_count(); }
 
 // Scratch (bytes) with which pf_gemm8p_launch may split the tail tiles of a problem along K (one slot per workgroup).

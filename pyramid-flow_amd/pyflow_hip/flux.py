@@ -381,6 +381,21 @@ class FluxEngine(DeviceModuleAPI):
             return self._run_launch_list(plan, mod)
         return out
 
+    def _groups_text(self, plan, tail, n_act, L_img, B, d):
+        """does a double block with this row geometry take the GROUPED form (text rows' tiles appended to the image rows'
+        persistent launches)?  True when every image GEMM of the block runs the persistent kernel as whole-round launches
+        (>= 192 tiles: what runs it without K-split scratch and with the QK epilogue).  Asked of the library once per
+        (plan, geometry, dispatch policy), not per block and forward."""
+        memo = plan.__dict__.setdefault("_group_memo", {})
+        key = (id(self), ops.POLICY_GEN, bool(tail), n_act)
+        if key not in memo:
+            lib = ops.L.load()
+            memo[key] = all(
+                lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8 and
+                -(-M_ // 256) * B * -(-N_ // 256) >= 192
+                for M_, N_, K_ in ((L_img, (2 if tail else 3) * d, d), (n_act, d, d), (n_act, 4 * d, d), (n_act, d, 4 * d)))
+        return memo[key]
+
     def _geometry(self, plan):
         w = self.w
         d, H = w.d, w.H
@@ -466,6 +481,7 @@ class FluxEngine(DeviceModuleAPI):
         join(0, 1)
 
         n_cur = plan.n_cur
+        prev_grouped = None
         for blk in dbl:
             mb = blk["mod"]
             pre_only = blk["pre_only"]
@@ -483,10 +499,14 @@ class FluxEngine(DeviceModuleAPI):
             # when all of the block's image GEMMs run the persistent kernel (pf_gemm_which == 8: from ~3 000 image rows on);
             # shorter sequences keep the two-stream form below.  No side stream, no joins, no K-split scratch.
             # (whole-round launches only: >= 192 tiles, what runs the persistent kernel without K-split scratch and with the QK epilogue)
-            if self.group_text and fuse and all(
-                    lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8 and
-                    -(-M_ // 256) * B * -(-N_ // 256) >= 192
-                    for M_, N_, K_ in ((L_img, (2 if tail else 3) * d, d), (n_act, d, d), (n_act, 4 * d, d), (n_act, d, 4 * d))):
+            grouped = self.group_text and fuse and self._groups_text(plan, tail, n_act, L_img, B, d)
+            # the two forms order the text rows differently (grouped: main stream only; two-stream: side stream between
+            # joins), and the choice is per block (an MMDiT's last block in tail form has fewer tiles than the others): where
+            # the form changes, the stream that takes over waits for the other one's work on `hidden` / `xn` / `big`
+            if prev_grouped is not None and prev_grouped != grouped:
+                join(0, 1) if prev_grouped else join(1, 0)
+            prev_grouped = grouped
+            if grouped:
                 nq_t = blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"]
                 nk_t = blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"]
                 if pre_only:

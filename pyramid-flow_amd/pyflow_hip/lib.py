@@ -93,6 +93,14 @@ class PyflowLibraryMissing(RuntimeError):
     pass
 
 
+def use_lab_library():
+    """tools/ and lab/ only: bind the measurement build (`make -C pyramid-flow_amd/csrc lab`: the same sources with the
+    lab-only switches of pf_gemm_set_policy compiled in) instead of the shipping library.  Call before the first load()."""
+    global LIB_PATH, _lib
+    assert _lib is None, "use_lab_library() must precede the first load()"
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpyflow_hip_lab.so")
+
+
 def load():
     """Load the shared library; raise loudly if it is absent (no CPU / torch fallback exists)."""
     global _lib

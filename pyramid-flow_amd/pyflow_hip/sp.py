@@ -255,161 +255,6 @@ class SPComm:
             raise RuntimeError("sequence-parallel self-test: wrong data delivered by " + ", ".join(wrong))
 
     def recv(self, t, src):
-        raise RuntimeError("LocalComm has no peers")
-
-
-class SPComm:
-    """all-to-all / all-reduce / broadcast over one torch.distributed group (the SP group = consecutive ranks,
-    sp_utils.py:42-47; inference uses world_size == sp_group_size, inference_multigpu.py:36)."""
-
-    def __init__(self, group=None):
-        assert dist.is_initialized(), "init the process group first (trainer_misc/utils.py:71-106 contract: env://)"
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
-        self.native = self.backend == "nccl"          # RCCL: device-side all_to_all_single with split sizes
-        self.recordable = False                       # torch.distributed calls cannot be recorded into a launch list
-
-    def _global(self, r):
-        return dist.get_global_rank(self.group, r) if self.group is not None else r
-
-    def all_to_all(self, recv, send, recv_splits, send_splits, async_op=False):
-        """recv / send: flat 1-D tensors; splits in elements, indexed by group rank.
-        async_op (RCCL only): the exchange runs on the communicator's own HIP stream, ordered after the work already
-        queued on the current stream; kernels launched next overlap with it until `.wait()` of the returned handle
-        (which makes the current stream wait, not the host).  Returns None when the exchange completed inline."""
-        if self.native:
-            return dist.all_to_all_single(recv[:sum(recv_splits)], send[:sum(send_splits)], recv_splits, send_splits,
-                                          group=self.group, async_op=async_op) if async_op else \
-                dist.all_to_all_single(recv[:sum(recv_splits)], send[:sum(send_splits)], recv_splits, send_splits,
-                                       group=self.group)
-        # gloo: no all_to_all; emulate with point-to-point (device tensors staged through the host)
-        dev = send.device
-        hs = send[:sum(send_splits)].cpu() if dev.type != "cpu" else send
-        hr = torch.empty(sum(recv_splits), dtype=recv.dtype)
-        so, ro = starts_of(send_splits), starts_of(recv_splits)
-        ops = []
-        for p in range(self.world):
-            if p == self.rank:
-                hr[ro[p]:ro[p] + recv_splits[p]].copy_(hs[so[p]:so[p] + send_splits[p]])
-                continue
-            if send_splits[p]:
-                ops.append(dist.P2POp(dist.isend, hs[so[p]:so[p] + send_splits[p]], self._global(p), self.group))
-            if recv_splits[p]:
-                ops.append(dist.P2POp(dist.irecv, hr[ro[p]:ro[p] + recv_splits[p]], self._global(p), self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        recv[:hr.numel()].copy_(hr)
-
-    def all_reduce(self, t):
-        if self.native or t.device.type == "cpu":
-            dist.all_reduce(t, group=self.group)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, group=self.group)
-            t.copy_(h)
-        return t
-
-    def broadcast(self, t, src=0):
-        if self.native or t.device.type == "cpu":
-            dist.broadcast(t, self._global(src), group=self.group)
-        else:
-            h = t.cpu()
-            dist.broadcast(h, self._global(src), group=self.group)
-            t.copy_(h)
-        return t
-
-    def barrier(self):
-        dist.barrier(group=self.group)
-
-    def send(self, t, dst):
-        """point-to-point (halo / strip exchange); stream-ordered on RCCL, blocking on gloo"""
-        if self.native or t.device.type == "cpu":
-            dist.send(t.contiguous(), self._global(dst), group=self.group)
-        else:
-            dist.send(t.contiguous().cpu(), self._global(dst), group=self.group)
-
-    def shift(self, send_t, recv_t):
-        """halo pass of the temporal context parallelism (video_vae/context_parallel_ops.py:76-114): send `send_t` to
-        rank+1 and receive rank-1's tensor into `recv_t`; no wrap-around (rank 0 receives nothing, the last rank sends
-        nothing).  One grouped isend/irecv pair, so neither side can block the other."""
-        staged = not (self.native or send_t.device.type == "cpu")
-        ops, hr = [], None
-        if self.rank + 1 < self.world:
-            s_ = send_t.contiguous()
-            ops.append(dist.P2POp(dist.isend, s_.cpu() if staged else s_, self._global(self.rank + 1), self.group))
-        if self.rank > 0:
-            hr = torch.empty(recv_t.shape, dtype=recv_t.dtype) if staged else recv_t
-            ops.append(dist.P2POp(dist.irecv, hr, self._global(self.rank - 1), self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if staged and hr is not None:
-            recv_t.copy_(hr)
-
-    def shift_start(self, send_t, recv_t):
-        """`shift` without waiting (RCCL only): returns a handle whose wait() makes the CURRENT stream wait for the received
-        halo -- the host does not block, kernels queued meanwhile overlap with the transfer.  None = completed inline."""
-        if not self.native:
-            self.shift(send_t, recv_t)
-            return None
-        ops = []
-        if self.rank + 1 < self.world:
-            ops.append(dist.P2POp(dist.isend, send_t.contiguous(), self._global(self.rank + 1), self.group))
-        if self.rank > 0:
-            ops.append(dist.P2POp(dist.irecv, recv_t, self._global(self.rank - 1), self.group))
-        if not ops:
-            return None
-        reqs = dist.batch_isend_irecv(ops)
-
-        class _H:
-            def wait(self_inner):
-                for r_ in reqs:
-                    r_.wait()
-        return _H()
-
-    def warm_p2p(self, device):
-        """Create the point-to-point channels the tile-parallel decode uses (neighbour strips r -> r+1, column blocks
-        r -> 0) before anything is timed: RCCL sets a pair's channel up lazily at its first send / recv."""
-        if self.world == 1:
-            return
-        t = torch.zeros(8, dtype=torch.float32, device=device)
-        r = torch.empty_like(t)
-        self.shift(t, r)
-        if self.rank == 0:
-            for src in range(1, self.world):
-                self.recv(r, src)
-        else:
-            self.send(t, 0)
-
-    def selftest(self, device):
-        """One round of every collective the sampling path uses, with known values: uneven all_to_all (rank r sends
-        p + 1 elements of value 100 r + p to rank p), all_reduce, broadcast, and the point-to-point channels.  Raises on a
-        wrong value; transport errors propagate."""
-        P, r = self.world, self.rank
-        send_spl = [p + 1 for p in range(P)]
-        recv_spl = [r + 1] * P
-        send = torch.cat([torch.full((p + 1,), float(100 * r + p)) for p in range(P)]).to(device=device, dtype=torch.bfloat16)
-        recv = torch.empty(sum(recv_spl), dtype=torch.bfloat16, device=device)
-        h = self.all_to_all(recv, send, recv_spl, send_spl, async_op=self.native)
-        if h is not None:
-            h.wait()
-        exp = torch.cat([torch.full((r + 1,), float(100 * p + r)) for p in range(P)]).to(torch.bfloat16)
-        if not torch.equal(recv.cpu(), exp):
-            raise RuntimeError("sequence-parallel self-test: all_to_all delivered wrong data")
-        t = torch.full((4,), float(r + 1), device=device)
-        self.all_reduce(t)
-        if not bool((t.cpu() == P * (P + 1) / 2).all()):
-            raise RuntimeError("sequence-parallel self-test: all_reduce delivered wrong data")
-        b = torch.full((3,), float(r), device=device)
-        self.broadcast(b, 0)
-        if not bool((b.cpu() == 0).all()):
-            raise RuntimeError("sequence-parallel self-test: broadcast delivered wrong data")
-        self.warm_p2p(device)
-
-    def recv(self, t, src):
         if self.native or t.device.type == "cpu":
             dist.recv(t, self._global(src), group=self.group)
         else:

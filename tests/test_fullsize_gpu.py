@@ -312,3 +312,17 @@ def test_mmdit_c4_length_forward_vs_oracle():
     err = rel_l2(out, ref)
     print(f"MMDiT d=1536 H=24 L=11888 (joint + context_pre_only block): forward rel-L2 vs oracle {err:.3e}")
     assert out.shape == ref.shape and err < 2e-2
+    # MIXED forms in one forward: the joint block is grouped (text tiles ride in the image launches, main stream only), the
+    # last block's 180-tile projections are not (two-stream form, text rows on the side stream).  Where the form changes the
+    # side stream has to wait for the main stream's writes of `hidden` / `xn` / `big` (round-5 advisor finding: it did not).
+    # The serial schedule (overlap_text = False: one stream, no race possible) is the reference; every launch mode of the
+    # overlapped schedule has to reproduce it BIT FOR BIT, repeatedly.
+    assert eng._groups_text(plan, False, Li, Li, 2, d) and not eng._groups_text(plan, True, plan.n_cur, Li, 2, d)
+    eng.overlap_text, eng.launch_mode = False, "eager"
+    serial = eng.forward_tokens(plan, clips_d, [386.0, 386.0], pooled, ctx).clone()
+    eng.overlap_text = True
+    for mode in ("eager", "list", "graph"):
+        eng.launch_mode = mode
+        for rep in range(4):
+            got = eng.forward_tokens(plan, clips_d, [386.0, 386.0], pooled, ctx)
+            assert torch.equal(got, serial), (mode, rep, (got - serial).abs().max().item())

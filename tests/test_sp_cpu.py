@@ -278,3 +278,52 @@ def test_unique_id_exchange_over_gloo(fail):
     else:
         assert [what for _, what, _ in res] == ["ok", "ok"] and res[0][2] == res[1][2] and len(res[0][2]) == 128, res
         assert any(res[0][2])
+
+
+def _selftest_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pyflow_hip import sp
+    comm = sp.init_sequence_parallel_group(sp_group_size=world)
+    issued = []
+    for name in ("all_to_all", "all_reduce", "broadcast", "warm_p2p"):
+        real = getattr(comm, name)
+
+        def spy(*a, _real=real, _name=name, **k):
+            issued.append(_name)
+            out = _real(*a, **k)
+            if _name == "all_to_all" and rank == 1:
+                a[0].zero_()                    # rank 1's transport "delivers" wrong data
+            return out
+        setattr(comm, name, spy)
+    try:
+        comm.selftest("cpu")
+        q.put((rank, "ok", issued))
+    except RuntimeError as e:
+        q.put((rank, str(e), issued))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_selftest_issues_every_collective_before_raising():
+    """SPComm.selftest (bench.py's first call at N > 1): a rank that sees wrong data still issues EVERY collective of the
+    round before it raises -- leaving at the first mismatch would park its peers inside the next collective until the
+    process group's timeout (round-5 advisor finding: a duplicated class definition had shadowed this behaviour)."""
+    import inspect
+    from pyflow_hip import sp
+    assert inspect.getsource(sp).count("class SPComm") == 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_selftest_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    order = ["all_to_all", "all_reduce", "broadcast", "warm_p2p"]
+    assert res[0] == (0, "ok", order), res
+    assert res[1][0] == 1 and "all_to_all" in res[1][1] and res[1][2] == order, res

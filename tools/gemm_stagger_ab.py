@@ -3,6 +3,7 @@ ABBA order, many short samples (box noise between consecutive samples is +-2...4
 import ctypes as C, statistics, sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+from pyflow_hip import lib as _labsel; _labsel.use_lab_library()      # needs `make -C pyramid-flow_amd/csrc lab`
 from pyflow_hip import ops, lib as L
 lib = L.load()
 dev = "cuda"

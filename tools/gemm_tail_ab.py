@@ -11,6 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pyramid-flow_amd"))
+from pyflow_hip import lib as _labsel; _labsel.use_lab_library()      # needs `make -C pyramid-flow_amd/csrc lab`
 from pyflow_hip import ops                                                                    # noqa: E402
 
 TOK = [240, 960, 3840]
