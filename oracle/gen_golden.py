@@ -242,6 +242,35 @@ def generate_bf16_fixture():
                os.path.join(OUT, "generate_tiny_latents_bf16.pt"))
 
 
+def generate_long_fixture():
+    """EIGHT units (temp = 8 -> 57 frames) through the UNMODIFIED reference: the autoregressive history (the previous
+    units' latents re-noised down the pyramid, pipeline.py:1112-1186) is seven units deep, so an error of one unit is fed
+    back seven times -- the longest trajectory compared before round 6 had three.  Both the fp32 run and the production
+    form (bf16 DiT + bf16 embeddings under CPU bf16 autocast, see generate_bf16_fixture) are stored."""
+    H, W, temp = 64, 128, 8
+    out = {}
+    for name in ("fp32", "bf16"):
+        dit = build_dit()
+        if name == "bf16":
+            dit = dit.to(torch.bfloat16)
+        pipe = rh.build_ref_pipeline(dit, build_vae(), **({"text_encoder": _Bf16TextEncoder()} if name == "bf16" else {}))
+        rh.patch_block_noise(pipe, rh.NoiseStream(1))
+        import contextlib
+        with torch.no_grad(), (torch.autocast("cpu", dtype=torch.bfloat16) if name == "bf16" else contextlib.nullcontext()):
+            lat = pipe.generate(prompt="a cat", height=H, width=W, temp=temp, num_inference_steps=[2, 2, 2],
+                                video_num_inference_steps=[2, 2, 2], guidance_scale=7.0, video_guidance_scale=5.0,
+                                generator=torch.Generator().manual_seed(0), output_type="latent")
+        te = pipe.text_encoder
+        pe, pm, pp = te("a cat, hyper quality, Ultra HD, 8K", None)
+        ne, nm, npool = te(NEG, None)
+        out[name] = dict(prompt_embeds=torch.cat([ne, pe]), prompt_mask=torch.cat([nm, pm]), pooled=torch.cat([npool, pp]),
+                         latents=lat)
+    assert out["bf16"]["latents"].dtype == torch.bfloat16 and out["fp32"]["latents"].shape[2] == temp
+    torch.save(dict(dit_cfg=synth.TINY_FLUX, dit_weight_seed=DIT_SEED, height=H, width=W, temp=temp, steps=[2, 2, 2],
+                    video_steps=[2, 2, 2], guidance=7.0, video_guidance=5.0, latent_seed=0, noise_seed=1, **out),
+               os.path.join(OUT, "generate_tiny_latents_8units.pt"))
+
+
 class _BatchTextEncoder:
     """the harness's stub prompt encoder over a LIST of prompts: one row per prompt (what the reference's encoders return)"""
 
@@ -304,6 +333,7 @@ if __name__ == "__main__":
     generate_fixture()
     generate_bf16_fixture()
     generate_batch_fixture()
+    generate_long_fixture()
     scheduler_fixture()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

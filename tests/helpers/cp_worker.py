@@ -57,9 +57,16 @@ def main():
         got = img.float().cpu().permute(3, 0, 1, 2)[None]
         e_oracle = rel_l2(got, ref)
         e_single = rel_l2(img.float().cpu(), single.float().cpu())
-        ok = (u8.shape == (1 + 8 * (T - 1), 48, 80, 3)) and e_oracle < 3e-2 and e_single < 2e-3
+        # EVERY output frame on its own (a wrong halo at one rank boundary, the first-frame rule of rank 0 --
+        # causal_vae.py:561-565 -- or a short last range -- 31 latent frames over 8 ranks: 4,4,4,4,4,4,4,3 -- would drown in
+        # the whole-clip norm)
+        pf = [rel_l2(img[f_].float().cpu(), single[f_].float().cpu()) for f_ in range(img.shape[0])]
+        po = [rel_l2(got[:, :, f_], ref[:, :, f_]) for f_ in range(img.shape[0])]
+        from pyflow_hip.sp import even_split
+        ok = (u8.shape == (1 + 8 * (T - 1), 48, 80, 3)) and e_oracle < 3e-2 and e_single < 2e-3 and max(pf) < 4e-3 and max(po) < 4e-2
         with open(out_path, "w") as f:
-            f.write(f"world={world} T={T} frames={tuple(u8.shape)} rel_l2_vs_oracle={e_oracle:.3e} vs_single={e_single:.3e}\n")
+            f.write(f"world={world} T={T} latent frames per rank {even_split(T, world)} frames={tuple(u8.shape)} "
+                    f"rel_l2_vs_oracle={e_oracle:.3e} (per frame max {max(po):.3e}) vs_single={e_single:.3e} (per frame max {max(pf):.3e})\n")
     else:
         ok = u8 is None and img is None
     dist.barrier()

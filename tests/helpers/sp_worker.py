@@ -32,7 +32,8 @@ def main():
         sd["pos_embed.pos_embed"] = synth.mmdit_state_dict(cfg, seed=3)["pos_embed.pos_embed"]
     else:
         cfg = dict(synth.TINY_FLUX, num_attention_heads=heads)
-        sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05, lively=True))
+        # (the released width -- 30 heads, d = 1920 -- keeps activations in range with the released init scale)
+        sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05 if heads <= 10 else 0.02, lively=True))
     g = torch.Generator().manual_seed(0)
     shapes = [(2, 4, 8), (1, 8, 16), (1, 16, 32), (1, 16, 32)]
     clips = [torch.randn(2, 16, *s, generator=g).to(torch.bfloat16).float().cuda() for s in shapes]

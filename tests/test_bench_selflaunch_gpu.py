@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra):
+def _run(extra, gpus=2, workload="smoke_128p_17f"):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "smoke_128p_17f",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--workload", workload,
                         "--tiny-model", "--no-cpu-baseline"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-4000:]
@@ -55,3 +55,27 @@ def test_self_launch_sequence_parallel_two_ranks_and_native_communicator_dry_run
 def test_self_launch_replicas_two_ranks():
     r = _run(["--parallelism", "replicas"])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "replicas" in r["config"]["parallelism"]
+
+
+def test_self_launch_eight_ranks_c5_context_parallel_decode():
+    """`python bench.py --gpus 8 --workload c5_vae_768p_241f` as the driver's scaling sweep issues it (tiny channel widths,
+    the real 768 x 1280 x 241-frame geometry): config C5's own partition -- 31 latent frames over 8 ranks = 4,4,4,4,4,4,4,3,
+    temporal context-parallel decode with a halo exchange per causal conv, frames gathered on rank 0 -- through the
+    self-launcher, the communicator self-test / fall-back ladder and the JSON line.  (Values: tests/test_sp_gpu.py
+    ::test_vae_context_parallel[8-31] compares every frame with the single-rank decode.)"""
+    r = _run([], gpus=8, workload="c5_vae_768p_241f")
+    assert r["n_gpus"] == 8 and r["launcher"] == "bench.py self-launch" and r["value"] > 0
+    assert r["config"]["parallelism"].startswith("cp8") and "context-parallel" in r["config"]["workload"]
+    assert r["communicator"].startswith("torch.distributed") and r["rccl_ranks"] == 0
+    assert r["metric"].startswith("PLUMBING RUN")
+
+
+def test_self_launch_eight_ranks_c3_sequence_parallel():
+    """`python bench.py --gpus 8` on the headline workload's own schedule (768p, 31 units x 3 stages, L = 368 ... 15 488,
+    960 forwards; tiny widths, 10 heads over 8 ranks = 2|2|1|1|1|1|1|1): the Ulysses engine over 8 ranks for every sequence
+    length of the job (uneven row chunks, text rows on rank 0 only, launch-list segments between the collectives) + the
+    tile-parallel decode of the 28 tiles over 8 ranks, end to end through the self-launcher."""
+    r = _run([], gpus=8, workload="c3_768p_241f")
+    assert r["n_gpus"] == 8 and r["config"]["parallelism"].startswith("sp8") and r["value"] > 0
+    assert r["scaling"] == "strong" and r["requested_parallelism"] == "auto"
+    assert r["phases"]["sampling_s"] > 0 and r["phases"]["decode_s"] > 0

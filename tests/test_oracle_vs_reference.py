@@ -387,6 +387,29 @@ def test_batch_fixture_is_the_references_and_rows_are_independent(ref, tmp_path,
     assert fresh["latents"].shape[0] == 2 and not torch.equal(fresh["latents"][0], fresh["latents"][1])
 
 
+def test_eight_unit_fixture_is_the_references_and_the_oracle_follows_it(ref, tmp_path, monkeypatch):
+    """tests/golden/generate_tiny_latents_8units.pt (round 6: eight autoregressive units, fp32 and the production bf16 form)
+    is reproduced bit for bit by re-running the unmodified reference, and the oracle's own host loop
+    (oracle/pipeline_oracle.py) follows the fp32 trajectory through all eight units."""
+    import os
+    from oracle import gen_golden as gg
+    from oracle.pipeline_oracle import generate_latents
+    from oracle.ref_harness import NoiseStream
+    committed = torch.load(os.path.join(gg.OUT, "generate_tiny_latents_8units.pt"))
+    monkeypatch.setattr(gg, "OUT", str(tmp_path))
+    gg.generate_long_fixture()
+    fresh = torch.load(os.path.join(str(tmp_path), "generate_tiny_latents_8units.pt"))
+    for k in ("fp32", "bf16"):
+        assert torch.equal(fresh[k]["latents"], committed[k]["latents"]) and fresh[k]["latents"].shape[2] == 8
+    g = committed
+    init = torch.randn((1, 16, g["temp"], g["height"] // 8, g["width"] // 8), generator=torch.Generator().manual_seed(g["latent_seed"]))
+    f = g["fp32"]
+    o = generate_latents(gg.synth_dit_sd(), g["dit_cfg"], f["prompt_embeds"], f["prompt_mask"], f["pooled"], init,
+                         NoiseStream(g["noise_seed"]).block_noise, g["steps"], g["video_steps"], g["guidance"], g["video_guidance"])
+    per_unit = [((o[:, :, u] - f["latents"][:, :, u]).norm() / f["latents"][:, :, u].norm()).item() for u in range(8)]
+    assert max(per_unit) < 1e-3, per_unit
+
+
 def test_reference_cfg_pair_equals_two_single_row_forwards(ref):
     """The premise of guidance parallelism (pyflow_hip/flux_cfg.py: one classifier-free-guidance branch per rank): in the
     UNMODIFIED reference the two rows of the `torch.cat([latents] * 2)` forward (pyramid_dit_for_video_gen_pipeline.py:747-776)

@@ -108,6 +108,32 @@ def test_generate_bf16_trajectory_vs_reference_fixture():
     assert rel_l2(lat.float().cpu(), ref) < 5e-2
 
 
+@pytest.mark.parametrize("form", ["fp32", "bf16"])
+def test_generate_eight_units_vs_reference_fixture(form):
+    """EIGHT autoregressive units (temp = 8 -> 57 frames; the product's job runs 31, the longest compared before round 6
+    had 3-4): every unit's latents against the UNMODIFIED reference's own run (oracle/gen_golden.py::generate_long_fixture,
+    re-derived bit for bit in tests/test_oracle_vs_reference.py).  `fp32`: fp32 prompt embeddings -> fp32 latents; `bf16`: the
+    production form (`_round = True`).  Seven re-noised history units deep an early unit's error is fed back seven times:
+    the bound stays SURVEY 8c's 5e-2 per unit, and the growth over the units is printed."""
+    from pyflow_hip import synth
+    from pyflow_hip.pipeline import PyramidDiTForVideoGeneration
+    from oracle.ref_harness import NoiseStream
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "generate_tiny_latents_8units.pt"))
+    f = g[form]
+    dsd = round_sd(synth.random_state_dict(synth.flux_param_shapes(g["dit_cfg"]), seed=g["dit_weight_seed"], std=0.05, lively=True))
+    pipe = PyramidDiTForVideoGeneration(dit_state_dict=dsd, dit_config=g["dit_cfg"], model_name="pyramid_flux", load_vae=False)
+    pipe.block_noise_fn = NoiseStream(g["noise_seed"]).block_noise
+    lat = pipe.generate(prompt_embeds=_embeds(f), height=g["height"], width=g["width"], temp=g["temp"],
+                        num_inference_steps=g["steps"], video_num_inference_steps=g["video_steps"],
+                        guidance_scale=g["guidance"], video_guidance_scale=g["video_guidance"],
+                        generator=torch.Generator().manual_seed(g["latent_seed"]), output_type="latent")
+    assert lat.shape == f["latents"].shape and lat.shape[2] == 8 and pipe._round == (form == "bf16")
+    ref = f["latents"].float()
+    per_unit = [rel_l2(lat[:, :, u].float().cpu(), ref[:, :, u]) for u in range(8)]
+    print(f"{form} trajectory, rel-L2 per unit vs the reference's 8-unit run:", [f"{e:.3e}" for e in per_unit])
+    assert max(per_unit) < 5e-2
+
+
 def test_generate_prompt_batch_vs_reference_fixture():
     """a list of two prompts (pyramid_dit_for_video_gen_pipeline.py:1049-1053): latents and block noise are drawn with batch
     shape from one stream, every sample runs under its own [negative | positive] context; each sample against the

@@ -113,10 +113,12 @@ def _launch(world, script, args, tmp_path):
     print(out.read_text())
 
 
-@pytest.mark.parametrize("world,heads,variant", [(2, 4, "flux"), (3, 4, "flux"), (3, 4, "mmdit"), (8, 10, "flux")])
+@pytest.mark.parametrize("world,heads,variant", [(2, 4, "flux"), (3, 4, "flux"), (3, 4, "mmdit"), (8, 10, "flux"), (8, 30, "flux")])
 def test_sp_multi_process_exchange(tmp_path, world, heads, variant):
     """uneven rows (L % world != 0) and uneven heads (4 over 3 ranks, 10 over 8 = the 2|2|1|1|1|1|1|1 analogue of the
-    benchmark's 30 heads over 8 ranks); miniFLUX and the SD3-style MMDiT; rank 0 also checks the CPU oracle.
+    benchmark's 30 heads over 8 ranks, and (round 6) the benchmark's own map: 30 heads at the released width d = 1920 over
+    8 ranks = 4|4|4|4|4|4|3|3, scripts/inference_multigpu.sh:9-23 with 8 GPUs); miniFLUX and the SD3-style MMDiT; rank 0
+    also checks the CPU oracle.
     (6 heads over 4 ranks ran through round 3 as well; dropped for the suite's wall time: 16 rank processes per file.)"""
     _launch(world, "sp_worker.py", [heads, variant], tmp_path)
 
@@ -134,9 +136,12 @@ def test_guidance_parallel_generate_two_ranks(tmp_path):
     _launch(2, "sp_pipeline_worker.py", ["cfg"], tmp_path)
 
 
-@pytest.mark.parametrize("world,T", [(2, 5), (3, 7)])
+@pytest.mark.parametrize("world,T", [(2, 5), (3, 7), (8, 31)])
 def test_vae_context_parallel(tmp_path, world, T):
-    """temporal context-parallel VAE decode (halo exchange per causal conv, uneven frame ranges) == single process"""
+    """temporal context-parallel VAE decode (halo exchange per causal conv, uneven frame ranges) == single process, frame by
+    frame.  (8, 31) is config C5's own partition (BASELINE.json configs[4]: 31 latent frames over 8 ranks = 4,4,4,4,4,4,4,3 ->
+    241 frames; video_vae/context_parallel_ops.py:14-114, modeling_causal_vae.py:540-567): the last rank's 3-frame range and
+    rank 0's first-frame rule included."""
     _launch(world, "cp_worker.py", [T], tmp_path)
 
 
