@@ -437,6 +437,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    ls0 = dict(getattr(getattr(pipe, "dit", None), "list_stats", None) or {})
     if sp is not None:
         sp.active = True
     if pipe is not None:
@@ -639,6 +640,18 @@ def main():
         res["whole_step_mfma_frac"] = round(45.94e15 * (1 if use_sp or world == 1 else world) / (dt / args.steps) / (world * PEAK_BF16_TFLOPS * 1e12), 4)
     if pipe is not None:
         res["config"]["launch_mode"] = getattr(pipe.dit, "launch_mode", "eager")
+        ls1 = getattr(pipe.dit, "list_stats", None)
+        if ls1:
+            # host-side cost of the launch lists / hipGraphs: recorded and captured once per (unit, stage) plan and kept across
+            # videos (pipeline.py: _plan, LRU over a whole schedule) -- inside the timed region only plans not seen in the
+            # warm-up are recorded (with --warmup 0: all of them)
+            d_ = {k: ls1[k] - ls0.get(k, 0) for k in ls1}
+            res["launch_lists"] = dict(
+                plans_recorded_total=ls1["records"], record_ms_per_plan=round(1e3 * ls1["record_s"] / max(ls1["records"], 1), 2),
+                graphs_instantiated_total=ls1["instantiates"],
+                instantiate_ms_per_plan=round(1e3 * ls1["instantiate_s"] / max(ls1["instantiates"], 1), 2),
+                recorded_in_timed_region=d_["records"], instantiated_in_timed_region=d_["instantiates"],
+                host_s_in_timed_region=round(d_["record_s"] + d_["instantiate_s"], 3), replays_in_timed_region=d_["replays"])
     # device memory the timed region needed (torch allocator high-water mark, max over ranks): the tiled decode runs four
     # tile lanes x four coalesced chunk windows, a hidden requirement of the headline number on a 288 GB part
     res["peak_mem_gib"] = round(peak_gib, 1)

@@ -10,6 +10,7 @@ out-projection reads `[O | mlp]` (= the reference's `cat([attn, mlp])`, flux_blo
 """
 import contextlib
 import ctypes as C
+import time
 
 import torch
 
@@ -210,6 +211,8 @@ class FluxEngine(DeviceModuleAPI):
         #   "eager": one ctypes call per launch;  "list": recorded once per plan, re-issued from C by one call;
         #   "graph": the same list captured into a hipGraph after its first replay (one hipGraphLaunch per forward)
         self.launch_mode = "graph"
+        # host-side bookkeeping of the launch lists: how many were recorded / captured and what that cost (bench.py reports it)
+        self.list_stats = dict(records=0, record_s=0.0, instantiates=0, instantiate_s=0.0, replays=0)
         self._ws_gen = 0                # bumped when a workspace buffer is re-allocated (recorded pointers go stale)
         self._listed_plans = None       # weak set of the plans that hold a launch list of this engine
 
@@ -339,9 +342,12 @@ class FluxEngine(DeviceModuleAPI):
             if ent is not None and ent[0] == key:
                 break
             cl = CommandList()
+            t_rec = time.perf_counter()
             with recording(cl):
                 self._run_blocks(plan, ms)
                 out = self._head(plan, ms)
+            self.list_stats["records"] += 1
+            self.list_stats["record_s"] += time.perf_counter() - t_rec
             if key[1] != self._ws_gen:        # a workspace buffer was (re)allocated while recording: pointers of the
                 continue                      # earlier entries may be stale -> record again, now without allocations
             plan._launch_list = ent = (key, cl, out)
@@ -364,11 +370,15 @@ class FluxEngine(DeviceModuleAPI):
             if getattr(self, "_cap_streams", None) is None:
                 self._cap_streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
             try:
+                t_inst = time.perf_counter()
                 cl.instantiate(*self._cap_streams)
+                self.list_stats["instantiates"] += 1
+                self.list_stats["instantiate_s"] += time.perf_counter() - t_inst
             except RuntimeError as e:         # no graph support for this sequence on this stack: keep replaying the list
                 import warnings
                 warnings.warn(f"launch list: hipGraph capture failed ({e}); falling back to list replay")
                 self.launch_mode = "list"
+        self.list_stats["replays"] += 1
         try:
             cl.run(main, side)
         except RuntimeError:

@@ -104,6 +104,7 @@ class PyramidDiTForVideoGeneration:
         self.sequential_offload_enabled = False
         self.block_noise_fn = None          # (bs, ch, t, h, w) -> CPU fp32 tensor; None = vectorised global-RNG draw
         self._plans = {}
+        self.plan_cache_size = 256
         self.timers = {}
 
     # ---- reference properties (:1261-1279)
@@ -178,12 +179,17 @@ class PyramidDiTForVideoGeneration:
     def _plan(self, shapes, mask):
         pair = bool(self.do_classifier_free_guidance)        # the rows of `mask` are one sample's [negative | positive] pair
         key = (tuple(shapes), mask.cpu().numpy().tobytes(), pair)
-        p = self._plans.get(key)
+        p = self._plans.pop(key, None)
         if p is None:
-            if len(self._plans) > 8:
-                self._plans.clear()
+            # LRU over a WHOLE schedule (the headline job has 93 (unit, stage) sequences, C2 / C4 48): the plan carries its
+            # recorded launch list / captured hipGraph (flux.py: _run_launch_list), so every video after the first one with
+            # the same geometry and prompt mask replays its graphs instead of re-recording and re-instantiating ~350 launches
+            # per plan (round 5 cleared this cache at 9 entries: every video re-recorded everything).  A plan is a few MB
+            # (RoPE table + mask vectors + the graph): 256 of them are noise next to 288 GB.
+            while len(self._plans) >= self.plan_cache_size:
+                self._plans.pop(next(iter(self._plans)))
             p = self.dit.make_plan(shapes, mask, cfg_pair=pair)
-            self._plans[key] = p
+        self._plans[key] = p          # (re)inserted last = most recently used
         return p
 
     def _pyramid(self, x, n_down):

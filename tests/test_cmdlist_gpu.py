@@ -109,3 +109,37 @@ def test_pipeline_latents_identical_across_launch_modes():
     assert torch.equal(lat["eager"][0], lat["eager"][1]), "the eager path itself is not reproducible"
     assert torch.equal(lat["eager"][0], lat["list"][0])
     assert torch.equal(lat["eager"][0], lat["graph"][0])
+
+
+def test_second_video_replays_the_first_videos_graphs_bit_identically():
+    """round 6: the pipeline's plan cache holds a whole schedule (LRU, pipeline.py: _plan), so the second generate() with the
+    same geometry and prompt mask records nothing and instantiates nothing -- every forward is a replay of a graph captured
+    during the first video -- and produces the same latents bit for bit (same seeds), also against the eager engine.  With
+    the round-5 cache (cleared at 9 plans) every video re-recorded ~350 launches per (unit, stage)."""
+    import bench
+    pipe, dcfg, dsd = bench.build_pipeline(DEV, tiny=True)
+    pipe.dit.launch_mode = "graph"
+    embeds = bench.synthetic_prompt(dcfg, DEV)
+
+    def video(seed=3):
+        torch.manual_seed(11)
+        return pipe.generate(prompt_embeds=embeds, height=64, width=128, temp=5, num_inference_steps=[2, 2, 2],
+                             video_num_inference_steps=[2, 2, 2], guidance_scale=7.0, video_guidance_scale=5.0,
+                             generator=torch.Generator().manual_seed(seed), output_type="latent").clone()
+    first = video()
+    s1 = dict(pipe.dit.list_stats)
+    assert s1["records"] == 15 == s1["instantiates"] == len(pipe._plans), (s1, len(pipe._plans))      # 5 units x 3 stages
+    second = video()
+    s2 = dict(pipe.dit.list_stats)
+    assert s2["records"] == s1["records"] and s2["instantiates"] == s1["instantiates"], (s1, s2)
+    assert s2["replays"] == 2 * s1["replays"] and pipe.dit.launch_mode == "graph"
+    assert torch.equal(first, second)
+    other = video(seed=4)                      # other noise through the same graphs: no re-record, another result
+    assert pipe.dit.list_stats["records"] == s1["records"] and not torch.equal(other, first)
+    pipe.dit.launch_mode = "eager"
+    assert torch.equal(video(), first)
+    # the cache is bounded: least recently used plans leave first
+    pipe.plan_cache_size = 4
+    pipe.dit.launch_mode = "graph"
+    video()
+    assert len(pipe._plans) == 4
