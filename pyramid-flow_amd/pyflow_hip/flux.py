@@ -235,6 +235,19 @@ class FluxEngine(DeviceModuleAPI):
                 p_.__dict__.pop("_launch_list", None)
         return t
 
+    def reserve(self, B, L, L_img, n_cur):
+        """grow the workspace to what a sequence of L rows (L_img image rows, n_cur of the current frame) needs, NOW: every
+        later forward of the job then finds its buffers in place and no recorded launch list goes stale mid-video"""
+        w, d = self.w, self.w.d
+        self._buf("hidden", B * L * d, torch.bfloat16)
+        self._buf("xn", B * L * d, torch.bfloat16)
+        self._buf("big", B * L * 7 * d, torch.bfloat16)
+        if not self.v_rowmajor:
+            self._buf("vT", B * w.H * 64 * ((L + 63) // 64 * 64 + 64), torch.bfloat16)
+        self._buf("tok", B * L_img * w.in_ch, torch.bfloat16)
+        self._buf("vtok", B * n_cur * w.proj_w.shape[0], torch.float32)
+        self._buf("mod_fixed", B * w.n_mod, torch.float32)
+
     def make_plan(self, clip_shapes, enc_mask, cfg_pair=False):
         """cfg_pair: the two rows of `enc_mask` are the [negative | positive] guidance pair of ONE sample (pipeline.py:747);
         only the guidance-parallel engine (flux_cfg.py) treats that differently from a genuine batch of 2"""

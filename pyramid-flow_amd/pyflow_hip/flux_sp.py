@@ -423,6 +423,10 @@ class FluxEngineSP(FluxEngine):
         self._ws["mod_fixed"][:n_mod].copy_(mod.reshape(-1)[:n_mod])
         ent[1].run(torch.cuda.current_stream())
 
+    def reserve(self, B, L, L_img, n_cur):
+        """(a rank's buffers hold its row chunk only and are sized per plan: nothing to pre-size)"""
+        return
+
     def _buf(self, name, numel, dtype):
         gen = self._ws_gen
         t = super()._buf(name, numel, dtype)

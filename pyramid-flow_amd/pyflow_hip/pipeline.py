@@ -192,6 +192,29 @@ class PyramidDiTForVideoGeneration:
         self._plans[key] = p          # (re)inserted last = most recently used
         return p
 
+    def _reserve_for(self, num_units, h0, w0, Lt):
+        """size the DiT's workspace for the LONGEST sequence of this job before its first forward (the last unit's last stage:
+        the history rule of _history, counted in tokens), so that no buffer is re-allocated half-way through the first video
+        -- a re-allocation invalidates every launch list / graph recorded so far (flux.py: _buf)."""
+        if not hasattr(self.dit, "reserve"):
+            return
+        n_st = len(self.stages)
+        tok = [(h0 * 2 ** i // 2) * (w0 * 2 ** i // 2) for i in range(n_st)]       # tokens per latent frame, stage 0 .. n_st-1
+        u, i_s = num_units - 1, n_st - 1
+        frames = [i_s]                              # the current frame's predecessor at this stage ...
+        cur, ptx = i_s, 1
+        while ptx < u:
+            cur = max(cur - 1, 0)
+            if cur == 0:
+                break
+            ptx += 1
+            frames.append(cur)
+        hist = sum(tok[c] for c in frames) if u >= 1 else 0
+        if u >= 1 and cur == 0 and ptx < u:
+            hist += (u - ptx) * tok[0]
+        L_img = hist + tok[i_s]
+        self.dit.reserve(2 if self.do_classifier_free_guidance else 1, Lt + L_img, L_img, tok[i_s])
+
     def _pyramid(self, x, n_down):
         """get_pyramid_latent (:555-570): x [C,T,H,W] fp32 device -> list low..high."""
         out = [x]
@@ -339,6 +362,7 @@ class PyramidDiTForVideoGeneration:
             x = y
         num_units = 1 + (temp - 1) // self.frame_per_unit
         generated = [[] for _ in range(nb)]
+        self._reserve_for(num_units, x.shape[-2], x.shape[-1], ctxs[0][1].shape[1])
         phases = getattr(self, "phase_times", None)      # bench.py: a dict that accumulates wall seconds per phase
         if phases is not None:
             torch.cuda.synchronize()

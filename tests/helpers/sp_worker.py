@@ -32,6 +32,8 @@ def main():
         sd["pos_embed.pos_embed"] = synth.mmdit_state_dict(cfg, seed=3)["pos_embed.pos_embed"]
     else:
         cfg = dict(synth.TINY_FLUX, num_attention_heads=heads)
+        if heads > 10:          # released width: one double + one single block (8 rank processes build it on one GPU)
+            cfg.update(num_layers=1, num_single_layers=1)
         # (the released width -- 30 heads, d = 1920 -- keeps activations in range with the released init scale)
         sd = round_sd(synth.random_state_dict(synth.flux_param_shapes(cfg), seed=3, std=0.05 if heads <= 10 else 0.02, lively=True))
     g = torch.Generator().manual_seed(0)

@@ -109,8 +109,9 @@ def _launch(world, script, args, tmp_path):
                 q.kill()
             raise
         logs.append(o.decode()[-2000:])
-    assert all(p.returncode == 0 for p in procs), f"return codes {[p.returncode for p in procs]}\n" + "\n----\n".join(logs)
-    print(out.read_text())
+    report = out.read_text() if out.exists() else "(no report written)"
+    assert all(p.returncode == 0 for p in procs), f"return codes {[p.returncode for p in procs]}\n{report}\n" + "\n----\n".join(logs)
+    print(report)
 
 
 @pytest.mark.parametrize("world,heads,variant", [(2, 4, "flux"), (3, 4, "flux"), (3, 4, "mmdit"), (8, 10, "flux"), (8, 30, "flux")])
