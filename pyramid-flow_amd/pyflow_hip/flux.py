@@ -247,6 +247,9 @@ class FluxEngine(DeviceModuleAPI):
         self._buf("tok", B * L_img * w.in_ch, torch.bfloat16)
         self._buf("vtok", B * n_cur * w.proj_w.shape[0], torch.float32)
         self._buf("mod_fixed", B * w.n_mod, torch.float32)
+        if w.dbl:
+            self._buf("splitk_txt", 8 << 20, torch.float32)
+        self._buf("gemm_tail", 16 << 20, torch.float32)
 
     def make_plan(self, clip_shapes, enc_mask, cfg_pair=False):
         """cfg_pair: the two rows of `enc_mask` are the [negative | positive] guidance pair of ONE sample (pipeline.py:747);

@@ -73,6 +73,7 @@ def test_self_launch_eight_ranks_c5_context_parallel_decode():
     self-launcher, the communicator self-test / fall-back ladder and the JSON line.  (Values: tests/test_sp_gpu.py
     ::test_vae_context_parallel[8-31] compares every frame with the single-rank decode.)"""
     r = _run([], gpus=8, workload="c5_vae_768p_241f")
+    print("8 ranks, c5:", r["ms_per_step"], "ms per step")
     assert r["n_gpus"] == 8 and r["launcher"] == "bench.py self-launch" and r["value"] > 0
     assert r["config"]["parallelism"].startswith("cp8") and "context-parallel" in r["config"]["workload"]
     assert r["communicator"].startswith("torch.distributed") and r["rccl_ranks"] == 0
@@ -86,6 +87,7 @@ def test_self_launch_eight_ranks_c3_geometry_sequence_parallel():
     collectives) + the tile-parallel decode of the 28 tiles over 8 ranks, end to end through the self-launcher.  (The full
     960-forward schedule takes > 15 min through gloo with 8 ranks on one GPU: measured in round 6, not run in the suite.)"""
     r = _run([], gpus=8, workload="c3geom_768p_17f")
+    print("8 ranks, c3 geometry:", r["ms_per_step"], "ms per step,", r["phases"])
     assert r["n_gpus"] == 8 and r["config"]["parallelism"].startswith("sp8") and r["value"] > 0
     assert r["scaling"] == "strong" and r["requested_parallelism"] == "auto"
     assert r["phases"]["sampling_s"] > 0 and r["phases"]["decode_s"] > 0
