@@ -345,6 +345,7 @@ extern "C" int pf_gemm_set_policy(int force) {
     if (force == 1000 || force == 1001) { pf_gemm8p_set_epi_mode(force - 1000); return 0; }     // Args::epi_mode
     if (force == 1202 || force == 1203) { g_stage3_enabled = force == 1203; return 0; }         // stages of the 128 x 128 kernel
     if (force == 1204 || force == 1205) { g_split_cap = force == 1204; return 0; }              // K split capped at 256 workgroups
+    if (force >= 100000 && force < 200000) { pf_gemm8p_set_stagger(-(force - 100000)); return 0; }   // stamp builds: window start (K-tile)
 #endif
     if (force >= 2000 && force <= 2128) {    // CUs the persistent launches leave to communication kernels
         if (pf_gemm8p_set_reserved_cus(force - 2000)) return set_err("pf_gemm_set_policy: the reservation leaves fewer than 64 CUs to the persistent kernel");

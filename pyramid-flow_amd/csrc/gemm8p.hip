@@ -66,6 +66,24 @@ constexpr int GROUP_M = 4;
         PF_FENCE();                       \
     } while (0)
 
+// ---- cycle stamps (LAB BUILD ONLY: -DPF_G8_STAMP=1 | 2; nothing of this exists in the shipping library).
+// A wave keeps 64 32-bit s_memtime stamps in the lanes of ONE register (v_writelane) and stores them at the end of the kernel:
+// no memory traffic and no added waits inside the loop -- a stamp is issued into an SGPR pair and read behind the
+// s_waitcnt lgkmcnt(0) that every load slot executes anyway.  Mode 1: one stamp per K-tile (release from phase 0's barrier =
+// start of its first MFMA phase), 64 K-tiles from -p.stagger on.  Mode 2: three stamps per phase (load slot start, arrival
+// at its barrier, release from it) of 4 K-tiles from -p.stagger on.  Read back with pf_lab_gemm8p_stamps.
+#ifdef PF_G8_STAMP
+__device__ unsigned g8_stamps[256 * 8 * 64];
+#define G8_ISSUE(sreg) asm volatile("s_memtime %0" : "=s"(sreg))
+#define G8_PUT(sreg, idx)                                                                                         \
+    do {                                                                                                          \
+        const int ix_ = (idx);                                                                                    \
+        unsigned sv_, sh_;          /* both halves are read HERE: the pair stays allocated until s_memtime has written it */ \
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(sv_), "=v"(sh_) : "s"((unsigned)(sreg)), "s"((unsigned)((sreg) >> 32))); \
+        stampv = lane == ix_ ? sv_ : stampv;                                                                      \
+    } while (0)
+#endif
+
 struct TileCoord { int b, m0, n0, g; };           // g = problem of a grouped launch (0 / 1)
 
 // How the `clen` tiles of one XCD's chunk are dealt to its `nslot` workgroups: n_full whole rounds, then r tail tiles, each
@@ -653,6 +671,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     // its stores): LA - 2 of them.  (Requesting two more units in front of the stores, so that two more slots run under the
     // store burst, was measured in round 5: neutral -- the stores retire within these four slots: DESIGN.md 3.)
     int skip_wait = 0;
+#ifdef PF_G8_STAMP
+    unsigned stampv = 0;
+    unsigned long long sA = 0, sB = 0, sC = 0;
+    const int st0 = p.stagger < 0 ? -p.stagger : 0;            // window start (K-tile index of this workgroup's stream)
+#endif
     auto end_of_load_slot = [&](int g, const int ph) {          // g = 4 gk + ph
         if (g + LA < U) {
             issue_unit(g + LA, (ph + LA) & 3);
@@ -661,35 +684,65 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#if PF_G8_STAMP == 2
+        G8_ISSUE(sB);
+#endif
         PF_BAR();
+#ifdef PF_G8_STAMP
+        if (PF_G8_STAMP == 2 || ph == 0) G8_ISSUE(sC);          // (never issued without a reader: the pair must stay allocated)
+        PF_FENCE();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PF_FENCE();
+#if PF_G8_STAMP == 2
+        {   // this slot's start (= release from the barrier behind the previous MFMA phase), the arrival at its barrier and the
+            // release from it (= start of the MFMA phase): issued and read inside this one slot, nothing is carried around the loop
+            const int ix = ((g >> 2) - st0) * 16 + ph * 4;
+            G8_PUT(sA, ix);
+            G8_PUT(sB, ix + 1);
+            G8_PUT(sC, ix + 2);
+            PF_FENCE();
+        }
+#elif PF_G8_STAMP == 1
+        if (ph == 0) { G8_PUT(sC, (g >> 2) - st0); PF_FENCE(); }          // one tick per K-tile: start of its first MFMA phase
+#endif
     };
 
     int c_tile = 0, c_kt = seg_begin(0), c_end = seg_end(0);
     for (int gk = 0; gk < GK; ++gk) {
         const int bs = gk & 1;
         const int g = 4 * gk;
+#if PF_G8_STAMP == 2
+#define G8_SLOT() G8_ISSUE(sA)
+#define G8_MFMA(q0, q1) mfma_quadrant(q0, q1)
+#else
+#define G8_SLOT()
+#define G8_MFMA(q0, q1) mfma_quadrant(q0, q1)
+#endif
         // phase 0: A sub 0 + B sub 0 | quadrant (A0, B0)
+        G8_SLOT();
         read_b(0, bs);
         PF_FENCE();
         read_a(0, bs);
         end_of_load_slot(g, 0);
-        mfma_quadrant(0, 0);
+        G8_MFMA(0, 0);
         PF_BAR();
         // phase 1: B sub 1 | (A0, B1)
+        G8_SLOT();
         read_b(1, bs);
         end_of_load_slot(g + 1, 1);
-        mfma_quadrant(0, 1);
+        G8_MFMA(0, 1);
         PF_BAR();
         // phase 2: A sub 1 | (A1, B1)
+        G8_SLOT();
         read_a(1, bs);
         end_of_load_slot(g + 2, 2);
-        mfma_quadrant(1, 1);
+        G8_MFMA(1, 1);
         PF_BAR();
         // phase 3: no fragment reads (B sub 0 is still resident) | (A1, B0)
+        G8_SLOT();
         end_of_load_slot(g + 3, 3);
-        mfma_quadrant(1, 0);
+        G8_MFMA(1, 0);
         // TILE BOUNDARY.  Group 1 runs one barrier behind group 0: with both epilogues in front of the loop's last barrier,
         // group 0's epilogue runs beside group 1's (short) load slot and group 1's beside group 0's next load slot -- one
         // after the other, the matrix pipe idle through both.  epi_mode bit 0: group 0 takes the barrier FIRST, so that its
@@ -713,6 +766,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         if (!late) PF_BAR();
     }
     if (wm == 0) PF_BAR();                 // matches group 1's extra barrier
+#ifdef PF_G8_STAMP
+    g8_stamps[(bid * 8 + wid) * 64 + lane] = stampv;
+#endif
 }
 
 // Second launch of a GEMM whose tail tiles were split along K: C = epi(sum over the parts, in part order, of the parked
@@ -869,6 +925,11 @@ int pf_gemm8p_mid_split(int tiles, int nk) {
     return tail_plan(clen, ncu >> 3, nk, g_tail_ov).sp;
 }
 
+#ifdef PF_G8_STAMP
+extern "C" int pf_lab_gemm8p_stamps(unsigned* dst_host) {          // [256 workgroups][8 waves][64 stamps]
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g8_stamps), sizeof(unsigned) * 256 * 8 * 64);
+}
+#endif
 void pf_gemm8p_set_tail_split(bool on) { g_tail_split = on; }
 void pf_gemm8p_set_tail_overhead(int k_tiles) { g_tail_ov = k_tiles; }
 void pf_gemm8p_set_stagger(int cycles) { g_stagger = cycles; }

@@ -93,12 +93,13 @@ class PyflowLibraryMissing(RuntimeError):
     pass
 
 
-def use_lab_library():
-    """tools/ and lab/ only: bind the measurement build (`make -C pyramid-flow_amd/csrc lab`: the same sources with the
-    lab-only switches of pf_gemm_set_policy compiled in) instead of the shipping library.  Call before the first load()."""
+def use_lab_library(name="lab"):
+    """tools/ and lab/ only: bind a measurement build (`make -C pyramid-flow_amd/csrc variant NAME=... DEFS=...`; `make lab` =
+    the same sources with the lab-only switches of pf_gemm_set_policy compiled in) instead of the shipping library.  Call
+    before the first load()."""
     global LIB_PATH, _lib
     assert _lib is None, "use_lab_library() must precede the first load()"
-    LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpyflow_hip_lab.so")
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "variants", name, "libpyflow_hip.so")
 
 
 def load():
