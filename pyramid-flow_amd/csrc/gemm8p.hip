@@ -347,7 +347,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             for (int kk = 0; kk < 2; ++kk) fb[s][jj][kk] = *(const bf16x8_t*)(base + jj * (16 * 128) + ch[kk]);
     };
     auto mfma_quadrant = [&](int sa, int sb) {
+#ifndef PF_G8_PRIO          // (lab variants: 1 = static priority 1 for the second wave group, no flips; 2 = no priority at all)
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -356,7 +358,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                 for (int jj = 0; jj < 2; ++jj)
                     acc[sa * 4 + f][sb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         fb[sb][jj][kk], fa[f][kk], acc[sa * 4 + f][sb * 2 + jj], 0, 0, 0);
+#ifndef PF_G8_PRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- epilogue of the compute tile, straight from the accumulators.  The flavour (residual, fp32 output, GELU) is a
@@ -659,11 +663,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 #pragma unroll
         for (int j = 0; j < LA; ++j)
             if (j < U) issue_unit(j, j & 3);
+#ifdef PF_G8_P2         // (two-phase form: slot 0 reads A sub 0 AND both B subs: units 0..2 have landed, 3..5 may be in flight)
+        if (U >= LA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
         if (U >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+#endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PF_BAR();
     if (wm == 1) PF_BAR();                 // group 1 runs one barrier behind group 0
+#if defined(PF_G8_PRIO) && PF_G8_PRIO == 1
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // ---- main loop over the K-tiles of all tiles of this workgroup
     // load slot g reads units <= g+1 and issues unit g + LA; then: all units <= g+2 of this wave have landed.
@@ -709,6 +720,53 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     };
 
     int c_tile = 0, c_kt = seg_begin(0), c_end = seg_end(0);
+#ifdef PF_G8_P2
+    // TWO phases per K-tile (lab variant): phase A = load slot {A sub 0, B sub 0, B sub 1: 16 fragment reads, units 4gk+6, 4gk+7}
+    // | 32 MFMAs (A0 x B0, A0 x B1); phase B = load slot {A sub 1: 8 reads, units 4gk+8, 4gk+9} | 32 MFMAs (A1 x B1, A1 x B0):
+    // FOUR barriers per K-tile instead of eight, 512-cycle MFMA phases.  Slot S = 2gk + h issues units 2S + 6, 2S + 7 (the
+    // same six units ahead); at its end the units the NEXT slot reads have landed: h = 0 -> unit 4gk+3 (four units = 8 pieces
+    // may be in flight), h = 1 -> units <= 4gk+6 (three units = 6 pieces).  A unit's LDS region is overwritten by unit + 8,
+    // issued in the slot after its last read by group 0 = the interval in which group 1's reads of it complete: every wave
+    // therefore waits for its fragment reads BEFORE its slot's barrier (lgkmcnt(0); the slot is the short side of the
+    // interval), so that no read is pending when the barrier releases the other group's DMA issue.
+    auto end_slot2 = [&](int S, const int h) {
+        if (2 * S + LA < U) {
+            issue_unit(2 * S + LA, h == 0 ? 2 : 0);
+            issue_unit(2 * S + LA + 1, h == 0 ? 3 : 1);
+            if (skip_wait > 0) --skip_wait;
+            else if (h == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PF_BAR();
+#ifdef PF_G8_STAMP
+        if (h == 0) {
+            G8_ISSUE(sC);
+            PF_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PF_FENCE();
+            G8_PUT(sC, (S >> 1) - st0);
+            PF_FENCE();
+        }
+#endif
+    };
+    for (int gk = 0; gk < GK; ++gk) {
+        const int bs = gk & 1;
+        read_b(0, bs);
+        read_b(1, bs);
+        PF_FENCE();
+        read_a(0, bs);
+        end_slot2(2 * gk, 0);
+        mfma_quadrant(0, 0);
+        mfma_quadrant(0, 1);
+        PF_BAR();
+        read_a(1, bs);
+        end_slot2(2 * gk + 1, 1);
+        mfma_quadrant(1, 1);
+        mfma_quadrant(1, 0);
+#else
     for (int gk = 0; gk < GK; ++gk) {
         const int bs = gk & 1;
         const int g = 4 * gk;
@@ -743,6 +801,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         G8_SLOT();
         end_of_load_slot(g + 3, 3);
         G8_MFMA(1, 0);
+#endif
         // TILE BOUNDARY.  Group 1 runs one barrier behind group 0: with both epilogues in front of the loop's last barrier,
         // group 0's epilogue runs beside group 1's (short) load slot and group 1's beside group 0's next load slot -- one
         // after the other, the matrix pipe idle through both.  epi_mode bit 0: group 0 takes the barrier FIRST, so that its
@@ -758,7 +817,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             PF_FENCE();
             epilogue(c_tile);
             PF_FENCE();
+#ifdef PF_G8_P2
+            skip_wait = 1;          // slot 2gk+2 needs units <= 4gk+7: issued (and drained) before the stores; the next one does not
+#else
             skip_wait = LA - 2;
+#endif
             ++c_tile;
             c_kt = seg_begin(c_tile);
             c_end = seg_end(c_tile);

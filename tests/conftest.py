@@ -11,6 +11,12 @@ for p in (ROOT, PKG):
 
 
 def pytest_configure(config):
+    # PF_TEST_VARIANT=<name>: run the suite against a measurement build of the library (pyramid-flow_amd/variants/<name>/,
+    # `make -C pyramid-flow_amd/csrc variant NAME=...`) -- how a lab variant of a kernel earns its parity before it replaces
+    # the shipping form.  Unset (the driver's runs): the shipping library.
+    if os.environ.get("PF_TEST_VARIANT"):
+        from pyflow_hip import lib
+        lib.use_lab_library(os.environ["PF_TEST_VARIANT"])
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (dev container only)")
 

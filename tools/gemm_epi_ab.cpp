@@ -185,7 +185,7 @@ int main(int argc, char** argv) {
         }
         bool same = true;
         for (size_t a = 1; a < arms.size(); ++a) same = same && sums[a] == sums[0];
-        printf("  bits %s\n", same ? "identical" : "DIFFER");
+        printf("  bits %s  checksum %016llx\n", same ? "identical" : "DIFFER", sums[0]);          // (compare across library builds too)
         fflush(stdout);
     }
     return 0;
