@@ -1,25 +1,31 @@
-// bf16 MFMA GEMM, persistent 256 x 256 block tile, v_mfma_f32_16x16x32_bf16, four ping-pong phases per K-tile.
+// bf16 MFMA GEMM, persistent 256 x 256 block tile, v_mfma_f32_16x16x32_bf16, two ping-pong phases per K-tile.
 //
 // Same contract as gemm.hip / gemm256.hip (C = epi(A . W^T), optional implicit-GEMM conv addressing).  Serves the
 // large DiT projections (flux_block.py:756-758, 816-835, 868-872, 914-942) and the wide VAE CausalConv3d layers
 // (modeling_causal_conv.py:116-146).  What differs from gemm256.hip, and why:
 //   * ONE persistent workgroup per CU walks a list of output tiles; the operand stream (LDS-DMA, 1 KiB pieces) is a
-//     single pipeline that runs five load slots (1.25 K-tiles) ahead of the MFMAs and CROSSES tile boundaries: while a
+//     single pipeline that runs six 16-KiB units (1.5 K-tiles) ahead of the MFMAs and CROSSES tile boundaries: while a
 //     tile's epilogue stores drain, the first K-tile of the next tile is already in LDS.  At K = 1920 (30 K-tiles) the
 //     un-overlapped prologue + epilogue of gemm256.hip cost 10-15 % of a tile.
-//   * The epilogue never touches LDS: the MFMAs compute C^T tiles (operands swapped), so a lane owns 4 consecutive
+//   * The epilogue never touches LDS memory: the MFMAs compute C^T tiles (operands swapped), so a lane owns 4 consecutive
 //     columns of one row per accumulator; the W rows are permuted on their way into LDS (the DMA source address is per
 //     lane) such that a lane's two accumulators of a column half are 8 CONSECUTIVE columns -> bias / GELU / gate*x+res
-//     and 16-byte stores straight from registers, no barrier, no staging strips.
-//   * 16x16x32 MFMAs on a 128 x 64 wave tile (2 x 4 waves): a K-tile is four phases of 16 MFMAs (one 64 x 32 quadrant
-//     x K = 64); the load slots of a K-tile read 12 / 4 / 8 / 0 fragments (A sub 0 + B sub 0, B sub 1, A sub 1, -: one
-//     A fragment set and both B sets stay in registers) and EVERY load slot issues ONE 16-KiB unit of the operand
-//     stream (2 pieces per wave), so the DMA instructions are spread evenly between the MFMA slots.
-//   * Two wave groups (the M halves) run one barrier apart: while one group issues its 16 MFMAs the other reads
-//     fragments and issues DMA (two barriers per phase).  One counted s_waitcnt vmcnt(8) per load slot: four units
-//     stay in flight across the barriers.  Invariant: at the end of load slot g (before its barrier) a wave's pieces
-//     of all units <= g+2 have landed; slot g reads units <= g+1; unit j+8 (same LDS region as unit j) is issued in
-//     slot j+2, two slots after the last read of unit j.
+//     on 16-byte register pieces, no barrier, no staging strips.
+//   * 16x16x32 MFMAs on a 128 x 64 wave tile (2 x 4 waves).  A K-tile is TWO phases of 32 MFMAs (round 6; rounds 2-5 ran
+//     four phases of 16): phase A = load slot {A sub 0, B sub 0, B sub 1: 16 fragment reads, two DMA units} | (A0 x B0),
+//     (A0 x B1); phase B = load slot {A sub 1: 8 reads, two DMA units} | (A1 x B1), (A1 x B0) -- one A fragment set and
+//     both B sets in registers, as before.  Measured with s_memtime stamps (tools/gemm8p_stamps.py,
+//     profiles/r06_gemm8p_stamps.log): 2 920 cycles per K-tile with eight barriers, 2 550 with four, where the matrix pipe
+//     needs 2 048 -- an interval costs ~75-125 cycles over its MFMAs whatever its length, so longer intervals waste less.
+//   * Two wave groups (the M halves) run one barrier apart: while one group issues its 32 MFMAs the other reads
+//     fragments and issues DMA (two barriers per phase).  Slot S = 2 gk + h issues units 2S + 6, 2S + 7; at its end the
+//     units the NEXT slot reads have landed: h = 0 -> unit 4gk + 3 (four units = 8 pieces of this wave may be in flight:
+//     s_waitcnt vmcnt(8)), h = 1 -> units <= 4gk + 6 (three units: vmcnt(6)).  A unit's LDS region is overwritten by
+//     unit + 8, issued in the slot after its last read by group 0 = the interval in which group 1's reads of it complete:
+//     every wave therefore waits for its fragment reads BEFORE its slot's barrier (lgkmcnt(0); the load slot is the short
+//     side of the interval), so that no read is pending when the barrier releases the other group's DMA issue.
+//   * STATIC PRIORITY: the second-dispatched wave group (waves 4-7) runs at s_setprio 1, no per-phase flips
+//     (MI355X_MICROARCH.md "two waves per SIMD" item 4): +1-2 % on every DiT shape.
 //   * TAIL SPLIT (round 3): the r tiles of an XCD's chunk that do not fill a last round of its nslot workgroups are split
 //     along K into sp equal ranges each (sp * r <= nslot), when the caller brings scratch (pf_gemm_desc.workspace,
 //     64 MiB): a workgroup's last segment is then a K range of a tail tile, whose raw fp32 sums it parks in its 256-KiB
@@ -36,6 +42,10 @@
 //     the asm drain that covers it; tests/test_kernel_isa.py checks the result in the ISA (16 stores in one run, no wait behind
 //     them, no scratch).  The two wave groups' epilogues run in the SAME barrier interval (group 0 takes the loop's last
 //     barrier first: epi_mode bit 0); waves without epilogue loads drain the DMA queue after their conversions.
+//   * COALESCED STORES (round 6).  The stamps put 8-10 k cycles of a tile boundary (13 % of a K = 1920 tile) into the ISSUE of
+//     the 16 stores per wave: in the accumulator layout adjacent lanes hold different rows, every store instruction was 64
+//     separate 16-byte writes (~270-530 cycles each).  The packed results are lane-permuted (ds_bpermute_b32) so that a quad
+//     of lanes writes 64 contiguous bytes, pipelined against the store issue: epilogue_tile's store loop.
 //   * GROUPED LAUNCH (round 5, pf_gemm_desc.A2 ...): the tile list may continue with the tiles of a second problem of the same
 //     N / K / flavour (the text stream of a double block); per-problem fields are read as p.pr[g] from the kernel arguments.
 // LDS: 2 K-tile buffers x (A 256 x 64 + W 256 x 64) bf16 = 128 KiB, XOR-swizzled like gemm256.hip (swizzle on the DMA
@@ -69,9 +79,9 @@ constexpr int GROUP_M = 4;
 // ---- cycle stamps (LAB BUILD ONLY: -DPF_G8_STAMP=1 | 2; nothing of this exists in the shipping library).
 // A wave keeps 64 32-bit s_memtime stamps in the lanes of ONE register (v_writelane) and stores them at the end of the kernel:
 // no memory traffic and no added waits inside the loop -- a stamp is issued into an SGPR pair and read behind the
-// s_waitcnt lgkmcnt(0) that every load slot executes anyway.  Mode 1: one stamp per K-tile (release from phase 0's barrier =
-// start of its first MFMA phase), 64 K-tiles from -p.stagger on.  Mode 2: three stamps per phase (load slot start, arrival
-// at its barrier, release from it) of 4 K-tiles from -p.stagger on.  Read back with pf_lab_gemm8p_stamps.
+// s_waitcnt lgkmcnt(0).  Mode 1: one stamp per K-tile (release from phase A's barrier = start of its first MFMA phase), 64
+// K-tiles from -p.stagger on.  Mode 3: five stamps per tile inside the epilogue.  (Mode 2 -- three stamps per phase of the
+// four-phase loop of rounds 2-5 -- went with that loop; its log is profiles/r06_gemm8p_stamps_four_phase.log.)  Read back with pf_lab_gemm8p_stamps.
 #ifdef PF_G8_STAMP
 __device__ unsigned g8_stamps[256 * 8 * 64];
 #define G8_ISSUE(sreg) asm volatile("s_memtime %0" : "=s"(sreg))
@@ -132,7 +142,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     // CU with run-time ring positions was built and measured in round 5: no gain at the tile boundaries, and the position
     // arithmetic in the load slots cost the main loop 4-9 %: profiles/r05_gemm8p_vs_r4_library_ring10.log.)
     constexpr int R = 8, LA = R - 2;
-    constexpr int INFLIGHT = 2 * (R - 4);       // pieces of this wave that may still be in flight at the end of a load slot
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;          // wave tile: rows wm*128 .. +128, columns wn*64 .. +64
@@ -331,6 +340,24 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     };
     load_bias(0);
     acc_from_bias();
+#ifdef PF_G8_STAMP
+    unsigned stampv = 0;
+    unsigned long long sA = 0, sC = 0;
+    const int st0 = p.stagger < 0 ? -p.stagger : 0;            // window start (K-tile index of this workgroup's stream)
+#endif
+#if PF_G8_STAMP == 3          // mode 3: five stamps per tile inside the epilogue (entry, conversions done, queue drained, stores
+    int e_tile = 0;             // issued, accumulators re-initialised) for this wave's first 12 tiles
+#define G8_EPI(k)                                                         \
+    do {                                                                  \
+        PF_FENCE();                                                       \
+        G8_ISSUE(sA);                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                \
+        G8_PUT(sA, e_tile < 12 ? e_tile * 5 + (k) : 64);                  \
+        PF_FENCE();                                                       \
+    } while (0)
+#else
+#define G8_EPI(k)
+#endif
 
     auto read_a = [&](int s, int bufsel) {
         const char* base = smem + bufsel * BUF_BYTES + a_rd + s * (64 * 128);
@@ -347,9 +374,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             for (int kk = 0; kk < 2; ++kk) fb[s][jj][kk] = *(const bf16x8_t*)(base + jj * (16 * 128) + ch[kk]);
     };
     auto mfma_quadrant = [&](int sa, int sb) {
-#ifndef PF_G8_PRIO          // (lab variants: 1 = static priority 1 for the second wave group, no flips; 2 = no priority at all)
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -358,9 +382,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                 for (int jj = 0; jj < 2; ++jj)
                     acc[sa * 4 + f][sb * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         fb[sb][jj][kk], fa[f][kk], acc[sa * 4 + f][sb * 2 + jj], 0, 0, 0);
-#ifndef PF_G8_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
     // ---- epilogue of the compute tile, straight from the accumulators.  The flavour (residual, fp32 output, GELU) is a
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         // the V / MLP column blocks of the QK flavour) the drain comes after the conversions, directly before the first store:
         // the units requested above land under the register work.
         const bool early = E_RES || E_F32 || (E_QK && qk_reg != 0);
+        G8_EPI(0);
         if (FOLD_BIAS && more_tiles) load_bias(seq + 1);
         auto load_col_params = [&](int hsel) {
             const int n_raw = wave_n0 + 32 * hsel + 8 * fq;
@@ -606,10 +628,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             }
         }
         if (!E_F32) {
+            G8_EPI(1);
             if (!early) {       // nothing of this wave's DMA is in flight across its stores (see the main loop's skip_wait)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PF_FENCE();
             }
+            G8_EPI(2);
             // THE NEXT TILE'S BIAS HAS LANDED (every path above drained the queue after requesting it) -- but the compiler does
             // not see the asm drains: it would guard the first use of nb0..3 (acc_from_bias, BEHIND the stores) with its own
             // s_waitcnt vmcnt(0), i.e. every epilogue would wait for its whole store burst to retire (rounds 2-4 did: the
@@ -619,20 +643,48 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                 asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3));
                 PF_FENCE();
             }
+            // COALESCED STORES.  In the accumulator layout a row's 64-byte piece sits in lanes {r, r+16, r+32, r+48}: ADJACENT lanes
+            // hold different rows (addresses ldc apart), so the memory pipeline sees 64 separate 16-byte writes per store
+            // instruction -- measured: ~270-530 cycles per store instruction and wave, 8-10 k cycles of a tile boundary
+            // (profiles/r06_gemm8p_stamps.log).  One lane permutation per packed register (ds_bpermute_b32: the LDS crossbar, no
+            // LDS memory, no barrier) turns lane L into (row L >> 2, piece L & 3): every quad of lanes then writes 64 contiguous
+            // bytes, the two halves of a 128-byte line back to back.  Software-pipelined by one item: the permutation of item
+            // i + 1 is in flight on the crossbar while item i's store issues.  Same values, same addresses, other lanes.
+            if (!mapped) {
+                const int psrc = (((lane & 3) << 4) | (lane >> 2)) << 2;
+                char* const crow2 = (char*)q.C + ((long long)tc.b * q.sC + (long long)(wave_m0 + (lane >> 2)) * p.ldc) * 2;
+                auto perm = [&](const u32x4_t v) {
+                    u32x4_t o;
 #pragma unroll
-            for (int hsel = 0; hsel < 2; ++hsel)
+                    for (int d_ = 0; d_ < 4; ++d_) o[d_] = (unsigned)__builtin_amdgcn_ds_bpermute(psrc, (int)v[d_]);
+                    return o;
+                };
+                u32x4_t cur = perm(outp[0][0]);
 #pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    const int m = wave_m0 + 16 * f + frow;
-                    if (mapped) {
-                        long long coff;
-                        const bool ok = out_off(m < q.M ? m : q.M - 1, ncol[hsel], coff) && m < q.M && ncol_ok[hsel];
-                        if (ok) *(u32x4_t*)((bf16_t*)q.C + coff) = outp[hsel][f];
-                    } else if (m < q.M && ncol_ok[hsel]) {
-                        *(u32x4_t*)(c_row + ((long long)(16 * f) * p.ldc + ncol[hsel]) * 2) = outp[hsel][f];
-                    }
-                    PF_FENCE();
+                for (int i = 0; i < 16; ++i) {              // i = 2 f + hsel
+                    u32x4_t nxt = cur;
+                    if (i + 1 < 16) nxt = perm(outp[(i + 1) & 1][(i + 1) >> 1]);
+                    const int f = i >> 1, hsel = i & 1;
+                    const int m2 = wave_m0 + 16 * f + (lane >> 2), n2 = wave_n0 + 32 * hsel + 8 * (lane & 3);
+                    if (m2 < q.M && n2 < p.n_valid) *(u32x4_t*)(crow2 + ((long long)(16 * f) * p.ldc + n2) * 2) = cur;
+                    cur = nxt;
                 }
+            } else {
+#pragma unroll
+                for (int hsel = 0; hsel < 2; ++hsel)
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        const int m = wave_m0 + 16 * f + frow;
+                        if (mapped) {
+                            long long coff;
+                            const bool ok = out_off(m < q.M ? m : q.M - 1, ncol[hsel], coff) && m < q.M && ncol_ok[hsel];
+                            if (ok) *(u32x4_t*)((bf16_t*)q.C + coff) = outp[hsel][f];
+                        } else if (m < q.M && ncol_ok[hsel]) {
+                            *(u32x4_t*)(c_row + ((long long)(16 * f) * p.ldc + ncol[hsel]) * 2) = outp[hsel][f];
+                        }
+                        PF_FENCE();
+                    }
+            }
         }
     };
     // part of a split tail tile (always this workgroup's last segment): park the raw sums, lane-linear 16-byte pieces,
@@ -649,86 +701,41 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
     auto epilogue = [&](int seq) {
         if (!CONV && tail_parks && seq >= n_full) { park(); return; }
         epilogue_tile(seq);
+        G8_EPI(3);
         // the accumulators restart (from the next tile's bias; zero after / before a parked segment) only now:
         // re-initialising them while the packed results are still waiting for their stores would keep 128 + 64 registers
         // alive at once
         PF_FENCE();
         acc_from_bias();
+        G8_EPI(4);
+#if PF_G8_STAMP == 3
+        ++e_tile;
+#endif
     };
 
-    // ---- prologue: units 0 .. LA - 1; units 0 and 1 (A sub 0, B sub 0 of the first K-tile: what load slot 0 reads) must have
-    //      landed before the first barrier
+    // ---- prologue: units 0 .. LA - 1; units 0 .. 2 (A sub 0 and both B subs of the first K-tile: what slot 0 reads) must have
+    //      landed before the first barrier, units 3 .. 5 (6 pieces of this wave) may be in flight
     setup_issue_tile(0);
     {
 #pragma unroll
         for (int j = 0; j < LA; ++j)
             if (j < U) issue_unit(j, j & 3);
-#ifdef PF_G8_P2         // (two-phase form: slot 0 reads A sub 0 AND both B subs: units 0..2 have landed, 3..5 may be in flight)
         if (U >= LA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#else
-        if (U >= LA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-#endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PF_BAR();
     if (wm == 1) PF_BAR();                 // group 1 runs one barrier behind group 0
-#if defined(PF_G8_PRIO) && PF_G8_PRIO == 1
+    // static priority for the second-dispatched wave group, no per-phase flips (MI355X_MICROARCH.md, "two waves per SIMD", item 4;
+    // measured +1-2 % on every DiT shape: profiles/r06_gemm8p_variants_ab.log)
     if (wm == 1) __builtin_amdgcn_s_setprio(1);
-#endif
 
-    // ---- main loop over the K-tiles of all tiles of this workgroup
-    // load slot g reads units <= g+1 and issues unit g + LA; then: all units <= g+2 of this wave have landed.
+    // ---- main loop over the K-tiles of all tiles of this workgroup (two phases per K-tile: file header)
     // skip_wait: load slots after an epilogue whose wait is already covered (the epilogue drained every unit issued before
-    // its stores): LA - 2 of them.  (Requesting two more units in front of the stores, so that two more slots run under the
-    // store burst, was measured in round 5: neutral -- the stores retire within these four slots: DESIGN.md 3.)
+    // its stores): one -- slot 2gk + 2 needs units <= 4gk + 7, all issued before the stores; the one after it does not.
+    // (Requesting more units in front of the stores, so that more slots run under the store burst, was measured in round 5
+    // on the four-phase form: neutral.)
     int skip_wait = 0;
-#ifdef PF_G8_STAMP
-    unsigned stampv = 0;
-    unsigned long long sA = 0, sB = 0, sC = 0;
-    const int st0 = p.stagger < 0 ? -p.stagger : 0;            // window start (K-tile index of this workgroup's stream)
-#endif
-    auto end_of_load_slot = [&](int g, const int ph) {          // g = 4 gk + ph
-        if (g + LA < U) {
-            issue_unit(g + LA, (ph + LA) & 3);
-            if (skip_wait > 0) --skip_wait;
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#if PF_G8_STAMP == 2
-        G8_ISSUE(sB);
-#endif
-        PF_BAR();
-#ifdef PF_G8_STAMP
-        if (PF_G8_STAMP == 2 || ph == 0) G8_ISSUE(sC);          // (never issued without a reader: the pair must stay allocated)
-        PF_FENCE();
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        PF_FENCE();
-#if PF_G8_STAMP == 2
-        {   // this slot's start (= release from the barrier behind the previous MFMA phase), the arrival at its barrier and the
-            // release from it (= start of the MFMA phase): issued and read inside this one slot, nothing is carried around the loop
-            const int ix = ((g >> 2) - st0) * 16 + ph * 4;
-            G8_PUT(sA, ix);
-            G8_PUT(sB, ix + 1);
-            G8_PUT(sC, ix + 2);
-            PF_FENCE();
-        }
-#elif PF_G8_STAMP == 1
-        if (ph == 0) { G8_PUT(sC, (g >> 2) - st0); PF_FENCE(); }          // one tick per K-tile: start of its first MFMA phase
-#endif
-    };
-
     int c_tile = 0, c_kt = seg_begin(0), c_end = seg_end(0);
-#ifdef PF_G8_P2
-    // TWO phases per K-tile (lab variant): phase A = load slot {A sub 0, B sub 0, B sub 1: 16 fragment reads, units 4gk+6, 4gk+7}
-    // | 32 MFMAs (A0 x B0, A0 x B1); phase B = load slot {A sub 1: 8 reads, units 4gk+8, 4gk+9} | 32 MFMAs (A1 x B1, A1 x B0):
-    // FOUR barriers per K-tile instead of eight, 512-cycle MFMA phases.  Slot S = 2gk + h issues units 2S + 6, 2S + 7 (the
-    // same six units ahead); at its end the units the NEXT slot reads have landed: h = 0 -> unit 4gk+3 (four units = 8 pieces
-    // may be in flight), h = 1 -> units <= 4gk+6 (three units = 6 pieces).  A unit's LDS region is overwritten by unit + 8,
-    // issued in the slot after its last read by group 0 = the interval in which group 1's reads of it complete: every wave
-    // therefore waits for its fragment reads BEFORE its slot's barrier (lgkmcnt(0); the slot is the short side of the
-    // interval), so that no read is pending when the barrier releases the other group's DMA issue.
     auto end_slot2 = [&](int S, const int h) {
         if (2 * S + LA < U) {
             issue_unit(2 * S + LA, h == 0 ? 2 : 0);
@@ -741,7 +748,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PF_BAR();
-#ifdef PF_G8_STAMP
+#if PF_G8_STAMP == 1
         if (h == 0) {
             G8_ISSUE(sC);
             PF_FENCE();
@@ -766,42 +773,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         end_slot2(2 * gk + 1, 1);
         mfma_quadrant(1, 1);
         mfma_quadrant(1, 0);
-#else
-    for (int gk = 0; gk < GK; ++gk) {
-        const int bs = gk & 1;
-        const int g = 4 * gk;
-#if PF_G8_STAMP == 2
-#define G8_SLOT() G8_ISSUE(sA)
-#define G8_MFMA(q0, q1) mfma_quadrant(q0, q1)
-#else
-#define G8_SLOT()
-#define G8_MFMA(q0, q1) mfma_quadrant(q0, q1)
-#endif
-        // phase 0: A sub 0 + B sub 0 | quadrant (A0, B0)
-        G8_SLOT();
-        read_b(0, bs);
-        PF_FENCE();
-        read_a(0, bs);
-        end_of_load_slot(g, 0);
-        G8_MFMA(0, 0);
-        PF_BAR();
-        // phase 1: B sub 1 | (A0, B1)
-        G8_SLOT();
-        read_b(1, bs);
-        end_of_load_slot(g + 1, 1);
-        G8_MFMA(0, 1);
-        PF_BAR();
-        // phase 2: A sub 1 | (A1, B1)
-        G8_SLOT();
-        read_a(1, bs);
-        end_of_load_slot(g + 2, 2);
-        G8_MFMA(1, 1);
-        PF_BAR();
-        // phase 3: no fragment reads (B sub 0 is still resident) | (A1, B0)
-        G8_SLOT();
-        end_of_load_slot(g + 3, 3);
-        G8_MFMA(1, 0);
-#endif
         // TILE BOUNDARY.  Group 1 runs one barrier behind group 0: with both epilogues in front of the loop's last barrier,
         // group 0's epilogue runs beside group 1's (short) load slot and group 1's beside group 0's next load slot -- one
         // after the other, the matrix pipe idle through both.  epi_mode bit 0: group 0 takes the barrier FIRST, so that its
@@ -811,17 +782,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         const bool late = tile_done && wm == 0 && (p.epi_mode & 1);
         if (late) PF_BAR();
         if (tile_done) {
-            // every DMA issued so far has had >= one MFMA slot; draining here makes the waits of the next four load
-            // slots unnecessary (their units were all issued before this point) and keeps the store traffic of the
-            // epilogue out of the counted waits
+            // every DMA issued so far has had >= one MFMA phase; draining here makes the wait of the next load slot
+            // unnecessary (its units were all issued before this point) and keeps the store traffic of the epilogue out
+            // of the counted waits
             PF_FENCE();
             epilogue(c_tile);
             PF_FENCE();
-#ifdef PF_G8_P2
-            skip_wait = 1;          // slot 2gk+2 needs units <= 4gk+7: issued (and drained) before the stores; the next one does not
-#else
-            skip_wait = LA - 2;
-#endif
+            skip_wait = 1;
             ++c_tile;
             c_kt = seg_begin(c_tile);
             c_end = seg_end(c_tile);

@@ -25,7 +25,7 @@ L.use_lab_library(variant)
 from pyflow_hip import ops                                                                       # noqa: E402
 
 so = L.load()
-mode = 2 if variant.endswith("2") else 1
+mode = 3 if variant.endswith("3") else 1
 D, Lseq = 1920, 15488
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
@@ -36,7 +36,11 @@ def run(N, K, gelu_from, window):
     W = (torch.randn(N, K, generator=g, device=dev) * 0.02).to(torch.bfloat16)
     Cc = torch.empty(2 * Lseq, N, dtype=torch.bfloat16, device=dev)
     bias = torch.zeros(N, device=dev)
-    ops.gemm_set_policy(100000 + window)
+    if os.environ.get("G8_POLICY"):          # e.g. 9 = desynchronised start (mode 1, window 0 only: the window rides in the same field)
+        assert window == 0
+        ops.gemm_set_policy(int(os.environ["G8_POLICY"]))
+    else:
+        ops.gemm_set_policy(100000 + window)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for it in range(3):
         if it == 2:
@@ -82,6 +86,24 @@ for name, N, K, gf in shapes:
         print("   workgroup 0 wave 0, first 40 K-tile periods:", [d32(int(t[i]), int(t[i + 1])) for i in range(40)])
         t = st[0, 4]
         print("   workgroup 0 wave 4, first 40 K-tile periods:", [d32(int(t[i]), int(t[i + 1])) for i in range(40)])
+    elif mode == 3:
+        st, ms, tf = run(N, K, gf, 0)
+        print(f"== {name}: {ms:.3f} ms = {tf:.0f} TFLOP/s (stamped build); epilogue of tiles 1..8 of each wave, cycles: "
+              "[entry -> conversions done | -> queue drained | -> stores issued | -> accumulators re-initialised]; "
+              "and from this tile's exit to the next tile's entry (= the main loop of a tile)")
+        for w in (0, 1, 4, 5):
+            seg = [[] for _ in range(5)]
+            for wg in range(0, 256, 4):
+                t = st[wg, w]
+                for tl in range(1, 8):
+                    e = [int(t[tl * 5 + k]) for k in range(5)]
+                    if 0 in e or int(t[(tl + 1) * 5]) == 0:
+                        continue
+                    for k in range(4):
+                        seg[k].append(d32(e[k], e[k + 1]))
+                    seg[4].append(d32(e[4], int(t[(tl + 1) * 5])))
+            print(f"   wave {w} (group {w // 4}): " + " | ".join(f"{statistics.median(x):.0f}" for x in seg[:4]) +
+                  f"   total {sum(statistics.median(x) for x in seg[:4]):.0f};  main loop between epilogues {statistics.median(seg[4]):.0f}")
     else:
         for window in (8, nk - 2):
             st, ms, tf = run(N, K, gf, window)
@@ -110,4 +132,4 @@ for name, N, K, gf in shapes:
                     rr = [r for r in rows if r[0] == kt]
                     tot = sum(r[2] + r[3] + (0 if r[4] != r[4] else r[4]) for r in rr)
                     print(f"     K-tile {window + kt}: " + "   ".join(f"ph{r[1]}: {r[2]:.0f} | {r[3]:.0f} | {r[4]:.0f}" for r in rr) + f"   sum {tot:.0f}")
-ops.gemm_set_policy(100000)
+ops.gemm_set_policy(0)
