@@ -244,7 +244,21 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     // the compiler knows, so in the one-pass form (load, add, store per piece: rounds 4) it kept every shortcut load behind the
     // previous store and guarded it with s_waitcnt vmcnt(0) -- 16 dependent load + store round trips per tile.
     u32x4_t outp[2][8];
-    auto out_off = [&](int hsel, int f, bool& ok) -> long long {
+    // COALESCED EPILOGUE TRAFFIC (round 6, as in gemm8p.hip).  In the accumulator layout the four 16-byte pieces of a pixel's 64
+    // bytes sit in lanes {x, x + 16, x + 32, x + 48}: adjacent lanes address different pixels (a channel pitch apart), every
+    // store / shortcut load was 64 separate 16-byte transactions (~270-530 cycles per instruction and wave in the GEMM).  The
+    // memory side uses the layout lane L = (pixel L >> 2, piece L & 3) -- a quad of lanes covers 64 contiguous bytes -- and
+    // the registers move between the two layouts through the LDS crossbar (ds_bpermute_b32: no LDS memory, no barrier).
+    const int fi2 = lane >> 2, fc2 = lane & 3;
+    const int to_mem = (((lane & 3) << 4) | (lane >> 2)) << 2;        // memory-layout lane L reads accumulator-layout lane (L & 3) 16 + (L >> 2)
+    const int to_acc = (((lane & 15) << 2) | (lane >> 4)) << 2;       // accumulator-layout lane (fc, fi) reads memory-layout lane 4 fi + fc
+    auto xperm = [&](const u32x4_t v, int src) {
+        u32x4_t o;
+#pragma unroll
+        for (int d_ = 0; d_ < 4; ++d_) o[d_] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)v[d_]);
+        return o;
+    };
+    auto out_off = [&](int hsel, int f, bool& ok, int fi, int fc) -> long long {
         const int n = 128 * nblk + 64 * wn + 32 * hsel + 8 * fc;
         // output placement of this lane's 8 filters (one group: Cg % 8 == 0): frame t st + pt (+ t_shift; < 0 = dropped),
         // pixel (y sh + ph, x sw + pw), channel cc
@@ -266,8 +280,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
 #pragma unroll
             for (int f = 0; f < 8; ++f) {
                 bool ok;
-                rr[f] = *(const u32x4_t*)(p.res + out_off(hsel, f, ok));
+                rr[f] = *(const u32x4_t*)(p.res + out_off(hsel, f, ok, fi2, fc2));
             }
+#pragma unroll
+            for (int f = 0; f < 8; ++f) rr[f] = xperm(rr[f], to_acc);
         }
         float gs[8], gq[8];
 #pragma unroll
@@ -310,14 +326,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
             }
         }
     }
+    {       // stores, pipelined by one item against the lane permutation of the next; the two halves of a pixel back to back
+        u32x4_t cur = xperm(outp[0][0], to_mem);
 #pragma unroll
-    for (int hsel = 0; hsel < 2; ++hsel)
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
+        for (int i = 0; i < 16; ++i) {               // i = 2 f + hsel
+            u32x4_t nxt = cur;
+            if (i + 1 < 16) nxt = xperm(outp[(i + 1) & 1][(i + 1) >> 1], to_mem);
             bool ok;
-            const long long off = out_off(hsel, f, ok);
-            if (ok) *(u32x4_t*)(p.Y + off) = outp[hsel][f];
+            const long long off = out_off(i & 1, i >> 1, ok, fi2, fc2);
+            if (ok) *(u32x4_t*)(p.Y + off) = cur;
+            cur = nxt;
         }
+    }
     if (do_stats) {
         BAR();
         if (tid < 256) {                              // (filter c, statistic k): add the four pixel-row waves of filter half wn_
