@@ -402,6 +402,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         const Prob& q = p.pr[CONV ? 0 : tc.g];
         const int wave_m0 = tc.m0 + wm * 128, wave_n0 = tc.n0 + wn * 64;
         const bool mapped = CONV && p.om.mode == 1;
+        // the memory-layout lane geometry (row ln >> 2, piece ln & 3, the two permutation sources) is derived from a LAUNDERED
+        // lane id: loop-invariant otherwise, the compiler computes it once in the prologue and keeps it alive -- or spills it
+        // -- across the main loop (setup_issue_tile does the same)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         // 0 = not a QK wave tile, 1 = K block, 2 = Q block (scalar)
         int qk_reg = 0;
         if (E_QK) {
@@ -526,6 +531,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         } else {
                             // one per-lane row pointer + a wave-uniform fragment stride: no per-fragment 64-bit
                             // offsets kept alive across the epilogue; rows past M are not read at all
+                            // one per-lane row pointer + a wave-uniform fragment stride: no per-fragment 64-bit
+                            // offsets kept alive across the epilogue; rows past M are not read at all.  (Round 6 tried these
+                            // loads in the coalesced memory layout + an inverse lane permutation, as the stores: the flavour
+                            // has no register left for it -- 12-92 bytes of scratch in every form tried.)
                             rbuf[f] = (u32x4_t){0u, 0u, 0u, 0u};
                             if (m < q.M) rbuf[f] = *(const u32x4_t*)(res_row + (long long)(16 * (f0 + f)) * p.ldr + n);
                         }
@@ -651,8 +660,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             // bytes, the two halves of a 128-byte line back to back.  Software-pipelined by one item: the permutation of item
             // i + 1 is in flight on the crossbar while item i's store issues.  Same values, same addresses, other lanes.
             if (!mapped) {
-                const int psrc = (((lane & 3) << 4) | (lane >> 2)) << 2;
-                char* const crow2 = (char*)q.C + ((long long)tc.b * q.sC + (long long)(wave_m0 + (lane >> 2)) * p.ldc) * 2;
+                const int psrc = (((ln & 3) << 4) | (ln >> 2)) << 2;
+                char* const crow2 = (char*)q.C + ((long long)tc.b * q.sC + (long long)(wave_m0 + (ln >> 2)) * p.ldc) * 2;
                 auto perm = [&](const u32x4_t v) {
                     u32x4_t o;
 #pragma unroll
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     u32x4_t nxt = cur;
                     if (i + 1 < 16) nxt = perm(outp[(i + 1) & 1][(i + 1) >> 1]);
                     const int f = i >> 1, hsel = i & 1;
-                    const int m2 = wave_m0 + 16 * f + (lane >> 2), n2 = wave_n0 + 32 * hsel + 8 * (lane & 3);
+                    const int m2 = wave_m0 + 16 * f + (ln >> 2), n2 = wave_n0 + 32 * hsel + 8 * (ln & 3);
                     if (m2 < q.M && n2 < p.n_valid) *(u32x4_t*)(crow2 + ((long long)(16 * f) * p.ldc + n2) * 2) = cur;
                     cur = nxt;
                 }
