@@ -380,7 +380,10 @@ int pf_set_err(const char* m);
 // Scratch of the 64-rows-per-wave pair: one int per wave of its grid (4 per workgroup) + the KV-split region (launches
 // with too few workgroups for the chip: attention_w64.h SPLIT / COMBINE): at most SPLIT_UNITS (query tile, part) units of
 // 4 waves x (18 KiB of parked sums + one flag).
-constexpr int SPLIT_UNITS = 1280;                 // 640 workgroups x 2 parts, or 256 x 4
+#ifndef PF_ATTN_SPLIT_NWG      // (lab builds sweep it: tools/attn_schedule_ab.py)
+#define PF_ATTN_SPLIT_NWG 640
+#endif
+constexpr int SPLIT_UNITS = 2 * PF_ATTN_SPLIT_NWG;     // SPLIT_NWG workgroups x 2 parts, or 256 x 4
 constexpr long long PART_BYTES = 18 * 1024;       // per wave
 static long long w64_flag_bytes(int B, int H, int L) { return (((long long)((L + 255) / 256) * H * B * 4 * (long long)sizeof(int)) + 255) & ~255ll; }
 extern "C" long long pf_attention_workspace_bytes(int B, int H, int L) {
@@ -390,7 +393,7 @@ extern "C" long long pf_attention_workspace_bytes(int B, int H, int L) {
 // parts per query tile for a launch of `nwg` 256-row workgroups over `ntiles` key tiles (1 = no split): launches of at most
 // 1.25 rounds of the chip's 512 workgroup slots are cut along the keys into chunks of at least 8 tiles
 static int w64_split(long long nwg, int ntiles) {
-    if (nwg >= 640 || ntiles < 16) return 1;
+    if (nwg >= PF_ATTN_SPLIT_NWG || ntiles < 16) return 1;
     int s_ = nwg >= 256 ? 2 : 4;
     while (s_ > 1 && (ntiles + s_ - 1) / s_ < 8) s_ >>= 1;
     return s_;

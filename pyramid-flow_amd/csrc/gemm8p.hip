@@ -416,27 +416,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
             } else if (p.qk_k0 >= 0 && wave_n0 >= p.qk_k0 && wave_n0 < p.qk_k0 + p.qk_d) qk_reg = 1;
             else if (p.qk_q0 >= 0 && wave_n0 >= p.qk_q0 && wave_n0 < p.qk_q0 + p.qk_d) qk_reg = 2;
         }
-        float qk_r[8];                                          // 1 / rms of the wave's rows (row fragment f, row frow)
-        if (E_QK) {
-            if (qk_reg) {
-#pragma unroll
-                for (int f = 0; f < 8; ++f) {
-                    float ssh[2];
-#pragma unroll
-                    for (int hsel = 0; hsel < 2; ++hsel) {
-                        float v[8], vb[8];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { v[r] = acc[f][2 * hsel][r]; v[4 + r] = acc[f][2 * hsel + 1][r]; }
-                        unpack8(pack8(v), vb);                  // the values the separate pass would read back
-                        float ss = qk_sumsq8(vb);
-                        ss += __shfl_xor(ss, 16);
-                        ss += __shfl_xor(ss, 32);
-                        ssh[hsel] = ss;
-                    }
-                    qk_r[f] = qk_rstd(ssh[0] + ssh[1], p.qk_eps);
-                }
-            }
-        }
         // output element offset of (row m, column n); false = nothing to store for this row
         auto out_off = [&](int m, int n, long long& coff) -> bool {
             if (mapped) {
@@ -468,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         // with them (fp32 output): the vector-memory queue is drained before the first conversion.  Otherwise (plain / GELU, and
         // the V / MLP column blocks of the QK flavour) the drain comes after the conversions, directly before the first store:
         // the units requested above land under the register work.
-        const bool early = E_RES || E_F32 || (E_QK && qk_reg != 0);
+        const bool early = E_RES || E_F32;          // (the QK wave tiles of flavour 8 have left through their own path above)
         G8_EPI(0);
         if (FOLD_BIAS && more_tiles) load_bias(seq + 1);
         auto load_col_params = [&](int hsel) {
@@ -501,19 +480,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         u32x4_t outp[2][8];
         // row fragments per batch: the residual flavour loads a column half's 8 residual pieces, waits once, converts them
         // (two drains per tile; 4-fragment batches = four drains measured 0.5-2.5 % slower)
-        constexpr int FB = E_QK ? 4 : 8;
+        constexpr int FB = 8;
 #pragma unroll
         for (int hsel = 0; hsel < 2; ++hsel) {
             if (E_RES) load_col_params(hsel);
             const int n = ncol[hsel];
-            f32x4_t qw0, qw1;                                   // QK: gains of this lane's 8 channels of the head
-            if (E_QK) {
-                if (qk_reg) {
-                    const float* w_ = (qk_reg == 1 ? q.qk_wk : q.qk_wq) + 32 * hsel + 8 * fq;
-                    qw0 = *(const f32x4_t*)w_;
-                    qw1 = *(const f32x4_t*)(w_ + 4);
-                }
-            }
             // wave-uniform (gelu_from is a multiple of 32, pf_gemm8p_supports): the column halves left of gelu_from skip
             // the activation's VALU work instead of computing and discarding it
             const bool do_act = E_ACT && (wave_n0 + 32 * hsel) >= p.gelu_from;
@@ -540,19 +511,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         }
                     }
                 }
-                f32x4_t qcs[FB][2];                             // QK: (cos, sin) of this lane's 4 pairs, per row fragment
-                if (E_QK) {
-                    if (qk_reg) {
-#pragma unroll
-                        for (int f = 0; f < FB; ++f) {
-                            const int m = wave_m0 + 16 * (f0 + f) + frow;
-                            const float* cs_ = p.qk_rope + ((long long)(q.qk_row0 + (m < q.M ? m : q.M - 1)) * 64 + 32 * hsel + 8 * fq);
-                            qcs[f][0] = *(const f32x4_t*)cs_;
-                            qcs[f][1] = *(const f32x4_t*)(cs_ + 4);
-                        }
-                    }
-                }
-                if ((hsel == 0 && f0 == 0 && early) || E_RES || (E_QK && qk_reg)) {
+                if ((hsel == 0 && f0 == 0 && early) || E_RES) {
                     // drains the DMA queue (see the main loop) and, for the residual / QK flavours, this batch's pieces
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PF_FENCE();
@@ -566,13 +525,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
 #pragma unroll
                         for (int f = 0; f < FB; ++f) asm volatile("" : "+v"(rbuf[f]));
                         asm volatile("" : "+v"(rb0), "+v"(rb1), "+v"(gate4[hsel][0]), "+v"(gate4[hsel][1]));
-                    }
-                    if (E_QK) {
-                        if (qk_reg) {
-#pragma unroll
-                            for (int f = 0; f < FB; ++f) asm volatile("" : "+v"(qcs[f][0]), "+v"(qcs[f][1]));
-                            asm volatile("" : "+v"(qw0), "+v"(qw1));
-                        }
                     }
                     PF_FENCE();
                     if (hsel == 0 && f0 == 0 && FOLD_BIAS && more_tiles && E_F32)
@@ -595,18 +547,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         if (do_act) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
-                        }
-                    }
-                    if (E_QK) {
-                        if (qk_reg) {
-                            float vb[8], w8[8], cs8[8];
-                            unpack8(pack8(v), vb);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                w8[e] = qw0[e]; w8[4 + e] = qw1[e];
-                                cs8[e] = qcs[fi][0][e]; cs8[4 + e] = qcs[fi][1][e];
-                            }
-                            qk_rope8(vb, qk_r[f], w8, cs8, qk_reg == 2 ? p.qk_qs : 1.f, v);
                         }
                     }
                     if (E_RES) {
@@ -638,11 +578,98 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
         }
         if (!E_F32) {
             G8_EPI(1);
+            // ---- flavour 8 (QK-RMSNorm + RoPE on the K / Q column blocks), round 6: everything behind the conversions happens in
+            // the MEMORY layout -- lane L = (row L >> 2, 16-byte piece L & 3), see COALESCED STORES below.  The packed bf16
+            // results (what the separate pass would read back) are lane-permuted in place; then, on the QK wave tiles, (i) the
+            // (cos, sin) rows are read as 128 contiguous bytes per quad of lanes (in the accumulator layout the 32 loads of a
+            // wave tile were 64 separate 16-byte reads each: most of a 23 k-cycle tile boundary), (ii) the four lanes that share
+            // a row's head are ADJACENT: the sum of squares' cross-lane adds are two DPP quad permutes instead of two trips
+            // through the LDS crossbar.  Same pairwise tree (piece ^ 1, piece ^ 2, then the two column halves) and the same
+            // per-lane arithmetic (common.h) as the separate pass: same bits.
+            constexpr int QB = 2;                                 // (4 items per batch: 56 bytes of scratch)
+            f32x4_t cs[2][QB][2], gw[2][2];                       // (cos, sin) rows: batches of QB items, double-buffered; gains
+            float rs[8];                                          // 1 / rms of row (fragment f, row ln >> 2)
+            const int frow2 = ln >> 2, pc = ln & 3;
+            auto load_cs = [&](int bt) {                          // item i = 2 f + hsel
+#pragma unroll
+                for (int k = 0; k < QB; ++k) {
+                    const int i = QB * bt + k;
+                    const int m2 = wave_m0 + 16 * (i >> 1) + frow2;
+                    const float* cs_ = p.qk_rope + ((long long)(q.qk_row0 + (m2 < q.M ? m2 : q.M - 1)) * 64 + 32 * (i & 1) + 8 * pc);
+                    cs[bt & 1][k][0] = *(const f32x4_t*)cs_;
+                    cs[bt & 1][k][1] = *(const f32x4_t*)(cs_ + 4);
+                }
+            };
+            if (E_QK) {
+                if (qk_reg) {
+                    load_cs(0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float* w_ = (qk_reg == 1 ? q.qk_wk : q.qk_wq) + 32 * h + 8 * pc;
+                        gw[h][0] = *(const f32x4_t*)w_;
+                        gw[h][1] = *(const f32x4_t*)(w_ + 4);
+                    }
+                }
+                const int psrc = (((ln & 3) << 4) | (ln >> 2)) << 2;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                    for (int d_ = 0; d_ < 4; ++d_)
+                        outp[i & 1][i >> 1][d_] = (unsigned)__builtin_amdgcn_ds_bpermute(psrc, (int)outp[i & 1][i >> 1][d_]);
+                if (qk_reg) {
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        float ssh[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float vb[8];
+                            unpack8(outp[h][f], vb);
+                            float ss = qk_sumsq8(vb);
+                            ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0xB1, 0xf, 0xf, false));   // piece ^ 1
+                            ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x4E, 0xf, 0xf, false));   // piece ^ 2
+                            ssh[h] = ss;
+                        }
+                        rs[f] = qk_rstd(ssh[0] + ssh[1], p.qk_eps);
+                    }
+                }
+            }
             if (!early) {       // nothing of this wave's DMA is in flight across its stores (see the main loop's skip_wait)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 PF_FENCE();
             }
             G8_EPI(2);
+            if (E_QK) {
+                if (qk_reg) {
+                    // (every register a load of this path filled is redefined behind the drain: the file's rule.  The packed items
+                    //  too: otherwise the compiler keeps the 128 UNPACKED floats of the sum-of-squares pass alive for the rotation)
+#pragma unroll
+                    for (int k = 0; k < QB; ++k) asm volatile("" : "+v"(cs[0][k][0]), "+v"(cs[0][k][1]));
+                    asm volatile("" : "+v"(gw[0][0]), "+v"(gw[0][1]), "+v"(gw[1][0]), "+v"(gw[1][1]));
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(outp[i & 1][i >> 1]));
+                    PF_FENCE();
+                    const float osc = qk_reg == 2 ? p.qk_qs : 1.f;
+#pragma unroll
+                    for (int bt = 0; bt < 16 / QB; ++bt) {
+                        if (bt + 1 < 16 / QB) load_cs(bt + 1);         // (ordinary loads with no store behind them: the compiler's own counted waits)
+                        PF_FENCE();
+#pragma unroll
+                        for (int k = 0; k < QB; ++k) {
+                            const int i = QB * bt + k;
+                            float vb[8], w8[8], cs8[8], v[8];
+                            unpack8(outp[i & 1][i >> 1], vb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                w8[e] = gw[i & 1][0][e]; w8[4 + e] = gw[i & 1][1][e];
+                                cs8[e] = cs[bt & 1][k][0][e]; cs8[4 + e] = cs[bt & 1][k][1][e];
+                            }
+                            qk_rope8(vb, rs[i >> 1], w8, cs8, osc, v);
+                            outp[i & 1][i >> 1] = pack8(v);
+                        }
+                        PF_FENCE();
+                    }
+                }
+            }
             // THE NEXT TILE'S BIAS HAS LANDED (every path above drained the queue after requesting it) -- but the compiler does
             // not see the asm drains: it would guard the first use of nb0..3 (acc_from_bias, BEHIND the stores) with its own
             // s_waitcnt vmcnt(0), i.e. every epilogue would wait for its whole store burst to retire (rounds 2-4 did: the
@@ -668,11 +695,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                     for (int d_ = 0; d_ < 4; ++d_) o[d_] = (unsigned)__builtin_amdgcn_ds_bpermute(psrc, (int)v[d_]);
                     return o;
                 };
-                u32x4_t cur = perm(outp[0][0]);
+                u32x4_t cur = E_QK ? outp[0][0] : perm(outp[0][0]);          // (flavour 8: permuted above, all of them)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {              // i = 2 f + hsel
                     u32x4_t nxt = cur;
-                    if (i + 1 < 16) nxt = perm(outp[(i + 1) & 1][(i + 1) >> 1]);
+                    if (i + 1 < 16) nxt = E_QK ? outp[(i + 1) & 1][(i + 1) >> 1] : perm(outp[(i + 1) & 1][(i + 1) >> 1]);
                     const int f = i >> 1, hsel = i & 1;
                     const int m2 = wave_m0 + 16 * f + (ln >> 2), n2 = wave_n0 + 32 * hsel + 8 * (ln & 3);
                     if (m2 < q.M && n2 < p.n_valid) *(u32x4_t*)(crow2 + ((long long)(16 * f) * p.ldc + n2) * 2) = cur;

@@ -31,7 +31,7 @@ dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
 
 
-def run(N, K, gelu_from, window):
+def run(N, K, gelu_from, window, qk=False):
     A = (torch.randn(2 * Lseq, K, generator=g, device=dev) * 1.0).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g, device=dev) * 0.02).to(torch.bfloat16)
     Cc = torch.empty(2 * Lseq, N, dtype=torch.bfloat16, device=dev)
@@ -45,8 +45,13 @@ def run(N, K, gelu_from, window):
     for it in range(3):
         if it == 2:
             ev[0].record()
+        qkd = None
+        if qk:          # the double blocks' K | V | Q projection: QK-RMSNorm + RoPE on the K and Q column blocks
+            rope = torch.randn(Lseq, 32, 2, generator=g, device=dev)
+            qkd = dict(rope=rope, wq=torch.ones(64, device=dev), wk=torch.ones(64, device=dev), d=D, k_col0=0, q_col0=2 * D, row0=0,
+                       eps=1e-6, q_scale=0.18)
         ops.gemm(A, W, Cc, Lseq, N, K, K, K, N, bias=bias, batch=2, strideA=Lseq * K, strideC=Lseq * N,
-                 gelu_from=gelu_from)
+                 gelu_from=gelu_from, qk=qkd)
     ev[1].record()
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1])
@@ -61,12 +66,13 @@ def d32(a, b):
     return (b - a) & 0xFFFFFFFF
 
 
-shapes = [("K|V|Q-like plain N=5760 K=1920", 3 * D, D, -1), ("MLP up GELU N=7680 K=1920", 4 * D, D, 0),
-          ("K|V|Q|MLP plain N=13440 K=1920", 7 * D, D, -1), ("plain N=1920 K=9600", D, 5 * D, -1)]
-for name, N, K, gf in shapes:
+shapes = [("K|V|Q-like plain N=5760 K=1920", 3 * D, D, -1, False), ("K|V|Q with the QK epilogue N=5760 K=1920", 3 * D, D, -1, True),
+          ("MLP up GELU N=7680 K=1920", 4 * D, D, 0, False),
+          ("K|V|Q|MLP plain N=13440 K=1920", 7 * D, D, -1, False), ("plain N=1920 K=9600", D, 5 * D, -1, False)]
+for name, N, K, gf, qk_ in shapes:
     nk = K // 64
     if mode == 1:
-        st, ms, tf = run(N, K, gf, 0)
+        st, ms, tf = run(N, K, gf, 0, qk_)
         print(f"== {name}: {ms:.3f} ms = {tf:.0f} TFLOP/s (stamped build); nk = {nk} K-tiles per tile")
         steady, bound = [], []
         for wg in range(0, 256, 8):
@@ -87,11 +93,11 @@ for name, N, K, gf in shapes:
         t = st[0, 4]
         print("   workgroup 0 wave 4, first 40 K-tile periods:", [d32(int(t[i]), int(t[i + 1])) for i in range(40)])
     elif mode == 3:
-        st, ms, tf = run(N, K, gf, 0)
+        st, ms, tf = run(N, K, gf, 0, qk_)
         print(f"== {name}: {ms:.3f} ms = {tf:.0f} TFLOP/s (stamped build); epilogue of tiles 1..8 of each wave, cycles: "
               "[entry -> conversions done | -> queue drained | -> stores issued | -> accumulators re-initialised]; "
               "and from this tile's exit to the next tile's entry (= the main loop of a tile)")
-        for w in (0, 1, 4, 5):
+        for w in (0, 1, 2, 4, 5, 6):
             seg = [[] for _ in range(5)]
             for wg in range(0, 256, 4):
                 t = st[wg, w]
@@ -106,7 +112,7 @@ for name, N, K, gf in shapes:
                   f"   total {sum(statistics.median(x) for x in seg[:4]):.0f};  main loop between epilogues {statistics.median(seg[4]):.0f}")
     else:
         for window in (8, nk - 2):
-            st, ms, tf = run(N, K, gf, window)
+            st, ms, tf = run(N, K, gf, window, qk_)
             print(f"== {name}: {ms:.3f} ms = {tf:.0f} TFLOP/s (stamped build); window = K-tiles {window}..{window + 3} of nk = {nk}")
             for w in (0, 4):
                 rows = []
