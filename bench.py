@@ -140,13 +140,14 @@ def c3_schedule():
 def cpu_baseline(dcfg, dsd, threads):
     """The reference path on the host cores, SURVEY 8d recipe, kind "port": the CPU fp32 oracle restatement (oracle/,
     pinned to the imported reference in the dev container) -- /root/reference itself does not exist on the GPU box, so
-    the reference cannot be imported where this runs.  Bounded sample (~20 s of CPU work):
+    the reference cannot be imported where this runs.  Bounded sample (~70 s of CPU work; every timing is the median of three
+    samples, their spread is reported):
       * one double-stream + one single-stream miniFLUX block at full width (d = 1920, 30 heads, CFG batch 2) inside a
         complete oracle forward at five sequence lengths of the schedule (unit 0 stages 0-2, unit 1 stages 0-1);
         t(L) = a L + b L^2 is fitted (GEMM / attention terms), residuals reported, and summed over the 960 forwards of
         the job x 12 (24 blocks = 12 x the sampled pair);
-      * one VAE tile-chunk: a 32 x 32 latent tile, one latent frame, full channel widths -> scaled to 28 tiles x 241
-        output frames (first-chunk cost per output frame);
+      * one VAE tile-chunk: a 32 x 32 latent tile, one latent frame, full channel widths (median of 3) -> scaled to 28 tiles
+        x 241 output frames (first-chunk cost per output frame);
       * the reference's per-block Python sampling loop of the block noise (pipeline.py:697-703): 2 000 draws timed,
         scaled to the 76 800 draws of each of the 30 video units."""
     import numpy as np
@@ -167,18 +168,23 @@ def cpu_baseline(dcfg, dsd, threads):
     pooled = torch.randn(2, dcfg["pooled_projection_dim"], generator=g)
     points = {368: [(1, 24, 40)], 608: [(1, 24, 40), (1, 24, 40)], 1088: [(1, 48, 80)],
               2048: [(1, 48, 80), (1, 48, 80)], 3968: [(1, 96, 160)]}
-    meas = []
+    meas, spread = [], []
     t_budget = time.time()
     with torch.no_grad():
         for L, shapes in points.items():
             clips = [torch.randn(2, 16, *s_, generator=g) for s_ in shapes]
             ts_ = torch.tensor([900.0, 900.0])
             flux_forward(sd, cfg, clips, enc, mask, pooled, ts_)          # warm-up (allocator, threads)
-            reps, t0 = 0, time.time()
-            while reps < 8 and (reps == 0 or time.time() - t0 < 2.5):
-                flux_forward(sd, cfg, clips, enc, mask, pooled, ts_)
-                reps += 1
-            meas.append((L, (time.time() - t0) / reps))
+            samples = []                                                  # three samples of >= ~3.5 s each; the MEDIAN is used
+            for _ in range(3):
+                reps, t0 = 0, time.time()
+                while reps < 12 and (reps == 0 or time.time() - t0 < 3.5):
+                    flux_forward(sd, cfg, clips, enc, mask, pooled, ts_)
+                    reps += 1
+                samples.append((time.time() - t0) / reps)
+            samples.sort()
+            spread.append((samples[2] - samples[0]) / samples[1])
+            meas.append((L, samples[1]))
     Ls = np.array([m[0] for m in meas], dtype=np.float64)
     tt = np.array([m[1] for m in meas], dtype=np.float64)
     A = np.stack([Ls, Ls * Ls], axis=1)
@@ -195,9 +201,12 @@ def cpu_baseline(dcfg, dsd, threads):
                 decoder_spatial_up_sample=vcfg["spatial_up_sample"], decoder_temporal_up_sample=vcfg["temporal_up_sample"])
     z = torch.randn(1, 16, 1, 32, 32, generator=gv)
     with torch.no_grad():
-        t0 = time.time()
-        vae_decode(vsd, ocfg, z)
-        t_tile = time.time() - t0
+        tl = []
+        for _ in range(3):
+            t0 = time.time()
+            vae_decode(vsd, ocfg, z)
+            tl.append(time.time() - t0)
+        t_tile = sorted(tl)[1]
     vae_s = t_tile * 28 * 241
     # block-noise loop of the reference (per-block MultivariateNormal.sample() in Python)
     # (the covariance is singular at gamma = 1/3: whether torch's Cholesky accepts it depends on the CPU, so the factor is
@@ -210,14 +219,72 @@ def cpu_baseline(dcfg, dsd, threads):
         dist_.sample()
     noise_s = (time.time() - t0) / 2000 * (15360 + 61440) * 30
     est = dit_s + vae_s + noise_s
-    return dict(value=float(241.0 / est), unit="frames/s", cores=threads, kind="port",
+    return dict(value=float(241.0 / est), unit="frames/s", cores=threads, kind="port", fit_residuals=[round(float(r), 3) for r in resid],
+                sample_spread=[round(x, 3) for x in spread],
                 sample=("oracle (CPU fp32 restatement of the reference; /root/reference is absent on the GPU box) on "
                         f"{threads} threads, {time.time() - t_budget:.0f} s of CPU work: 1 double + 1 single miniFLUX block at "
                         f"full width inside a complete forward at L = {[m[0] for m in meas]} -> {[round(m[1], 3) for m in meas]} s; "
+                        f"(median of 3 samples per length, (max - min) / median {[round(x, 3) for x in spread]}); "
                         f"fit t = {coef[0]:.3e} L + {coef[1]:.3e} L^2 (relative residuals {[round(float(r), 3) for r in resid]}), "
                         f"summed over the 960 forwards x 12 = {dit_s:.0f} s DiT; one 32x32x1-latent VAE tile-chunk {t_tile:.2f} s "
                         f"x 28 tiles x 241 frames = {vae_s:.0f} s; reference block-noise Python loop {noise_s:.0f} s; "
                         f"total {est:.0f} s per 241-frame video"))
+
+
+def pmc_traffic_in_run(timeout_s=300):
+    """HBM-side traffic of the DiT's kernels MEASURED in this run (rank 0, N = 1): two child passes of
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE` (separate passes, nothing else traced: MI355X_MICROARCH.md, HBM section)
+    over tools/forward_only.py -- two full-width forwards at the headline sequence L = 15 488, the launch shapes of the timed
+    region's heaviest (unit, stage).  Returns ({kernel name: {launches, fetch_kb, write_kb, hbm_bytes_per_launch}}, note) in the
+    format of profiles/rNN_pmc_forward_maxL.json, or (None, reason): the caller then replays the committed profile and says so.
+    hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB (gfx950 reports half of wide coalesced reads in FETCH_SIZE)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"pf_pmc_{ctr}_", dir="/tmp")
+        try:
+            pr = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--",
+                                 sys.executable, os.path.join(ROOT, "tools", "forward_only.py"), "2"], cwd="/tmp",
+                                env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"{ctr} pass wrote no counter file (rc {pr.returncode}): {pr.stderr.decode()[-200:]}"
+            per = collections.OrderedDict()           # dispatch -> (kernel, summed counter over its rows)
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] != ctr:
+                        continue
+                    e = per.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], 0.0])
+                    e[1] += float(r["Counter_Value"])
+            acc = collections.defaultdict(list)
+            for name, v in per.values():
+                acc[name].append(v)
+            for name, lst in acc.items():
+                vals.setdefault(name, {})[ctr] = (len(lst), sum(lst) / len(lst))
+        except subprocess.TimeoutExpired:
+            return None, f"{ctr} pass exceeded {timeout_s} s"
+        except Exception as e:          # noqa: BLE001
+            return None, f"{ctr} pass failed: {e!r}"[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for name, dct in vals.items():
+        if "FETCH_SIZE" in dct and "WRITE_SIZE" in dct:
+            f_, w_ = dct["FETCH_SIZE"][1], dct["WRITE_SIZE"][1]
+            out[name] = dict(launches=dct["FETCH_SIZE"][0], fetch_kb=f_, write_kb=w_, hbm_bytes_per_launch=(2 * f_ + w_) * 1024)
+    if not out:
+        return None, "no kernel carried both counters"
+    return out, ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch, MEASURED IN THIS RUN: two rocprofv3 --kernel-trace --pmc child passes "
+                 "(FETCH_SIZE, WRITE_SIZE) over tools/forward_only.py = 2 full-width forwards at L=15488 on this GPU, after the "
+                 "timed region; mean over this kernel's launches; counted at the L2<->fabric interface incl. Infinity-Cache hits")
 
 
 def self_launch(n):
@@ -276,6 +343,9 @@ def main():
     ap.add_argument("--workload", default="c3_768p_241f", choices=list(WORKLOADS))
     ap.add_argument("--tiny-model", action="store_true", help="tiny random model (plumbing check, not a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic in the run (N = 1, headline "
+                         "workload); the committed profile is replayed instead and the line says so")
     ap.add_argument("--profile-period", type=int, default=7)
     ap.add_argument("--group-text", default="auto", choices=["auto", "on", "off"],
                     help="double blocks: the text stream's GEMMs inside the image stream's persistent launches (pf_gemm_desc.A2 ..., "
@@ -556,6 +626,13 @@ def main():
         pmc_blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]
     except Exception:
         pm, pmc_blob = {}, None
+    pmc_live_note, pmc_live_fail = None, None
+    if world == 1 and not args.no_pmc and not args.tiny_model and args.workload.startswith("c3_"):
+        live, why = pmc_traffic_in_run()
+        if live is not None:
+            pm, pmc_live_note = live, why
+        else:
+            pmc_live_fail = why
 
     try:
         with open(os.path.join(ROOT, "profiles", PMC_PROFILE_VAE), "rb") as f:
@@ -608,7 +685,11 @@ def main():
         if k_.startswith("vae:") and r_.get("traffic") is not None:
             r_["traffic_note"] = (f"(2*FETCH_SIZE + WRITE_SIZE) per launch from rocprofv3 --pmc passes over the same tile-chunk "
                                   f"window (profiles/{PMC_PROFILE_VAE}, git blob {pmc_blob_vae}); REPLAYED, not measured in this run")
-    if roof is not None and roof["traffic"] is not None:
+    if roof is not None and roof["traffic"] is not None and pmc_live_note is not None:
+        roof["traffic_note"] = pmc_live_note
+    elif roof is not None and roof["traffic"] is not None:
+        if pmc_live_fail:
+            roof["traffic_in_run_failed"] = pmc_live_fail
         roof["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB per launch of this kernel (gfx950 FETCH correction), mean over "
                                 f"the launches of one full-width forward at L=15488; REPLAYED from profiles/{PMC_PROFILE} "
                                 f"(git blob {pmc_blob}), not measured in this run; "

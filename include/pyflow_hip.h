@@ -28,8 +28,9 @@ const char* pf_last_error(void);
 /* ABI version of THIS header.  pf_version() returns the version the library was built with; a caller compares the two
  * before its first launch (a descriptor struct that grew -- 2 -> 3: pf_attn_desc.workspace / workspace_bytes,
  * pf_conv_desc.gn_stats / gn_C; 3 -> 4: pf_gemm_desc.qk_*; 4 -> 5: pf_gemm_desc.qk_head_stride; 5 -> 6: the second
- * problem of a grouped GEMM launch -- would otherwise be read past its end). */
-#define PF_ABI_VERSION 6
+ * problem of a grouped GEMM launch -- would otherwise be read past its end; 6 -> 7: no struct grew, pf_shift_caches accepts
+ * n_frames = 0). */
+#define PF_ABI_VERSION 7
 int pf_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: 0 pf_gemm_desc, 1 pf_conv_desc, 2 pf_attn_desc,
  * 3 pf_attn_small_desc (-1 otherwise) -- lets a foreign-language binding (ctypes / cgo / JNI struct mirrors) verify its
@@ -291,7 +292,8 @@ int pf_gn_apply(const void* x, void* y, const double* stats, const float* gamma,
 int pf_softmax_rows(void* S, int ld, int n_valid, int n_cols, int rows, float scale, pf_stream_t stream);
 /* every conv-cache update of one decode / encode chunk in ONE launch (the `cache_front_feat` bookkeeping of
  * CausalConv3d.forward, modeling_causal_conv.py:128-143): for buffer i (bf16 [2 + T][frame_elems[i]], HOST arrays of
- * `count` <= 64 entries) the two leading cache slots receive the last two of the 2 + n_frames[i] frames. */
+ * `count` <= 64 entries) the two leading cache slots receive the last two of the 2 + n_frames[i] frames; n_frames[i] = 0
+ * (ABI 7) zeroes them instead: the causal zero padding in front of a clip's first chunk (:128-131). */
 int pf_shift_caches(int count, const void* const* bufs, const long long* frame_elems, const int* n_frames, pf_stream_t stream);
 /* latent z [C][T][H][W] fp32, frames t0..t0+nt, window (h0,w0,th,tw) -> channels-last bf16 with per-frame-class
  * affine (frame 0: a0 z + b0, others a1 z + b1: decode_latent un-normalisation, pipeline.py:1226-1230) */

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void rgb_to_yuv420_kernel(const unsigned char*
 
 // All cache-slot updates of one chunk in ONE launch (cache_front_feat update of every CausalConv3d,
 // modeling_causal_conv.py:132,143): buffer b: slots[0:2] <- frames [n, n+2) of slots[0 : 2+n)  (n >= 2), or
-// slot0 <- slot1, slot1 <- slot2 (n == 1).  blockIdx.y = buffer, 16-byte pieces over the 2 frames.
+// slot0 <- slot1, slot1 <- slot2 (n == 1), or both slots <- 0 (n == 0: a new clip starts, causal_conv.py:128-131).  blockIdx.y = buffer, 16-byte pieces over the 2 frames.
 struct ShiftList { int count; unsigned long long ptr[64]; long long fs[64]; int n[64]; };
 __global__ __launch_bounds__(256) void shift_caches_kernel(const ShiftList L) {
     const int b = blockIdx.y;
@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256) void shift_caches_kernel(const ShiftList L) {
     const long long fs8 = L.fs[b] >> 3;            // 16-byte pieces per frame
     const int n = L.n[b];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < fs8; i += (long long)gridDim.x * blockDim.x) {
-        if (n >= 2) {
+        if (n == 0) {                              // reset: the causal zero padding of a clip's first chunk
+            base[i] = (u32x4_t){0u, 0u, 0u, 0u};
+            base[fs8 + i] = (u32x4_t){0u, 0u, 0u, 0u};
+        } else if (n >= 2) {
             base[i] = base[(long long)n * fs8 + i];
             base[fs8 + i] = base[(long long)(n + 1) * fs8 + i];
         } else {
@@ -431,7 +434,7 @@ extern "C" int pf_shift_caches(int count, const void* const* bufs, const long lo
     L.count = count;
     long long fs_max = 0;
     for (int i = 0; i < count; ++i) {
-        if (!bufs[i] || frame_elems[i] % 8 || n_frames[i] < 1) return pf_set_err("pf_shift_caches: bad entry");
+        if (!bufs[i] || frame_elems[i] % 8 || n_frames[i] < 0) return pf_set_err("pf_shift_caches: bad entry");
         L.ptr[i] = (unsigned long long)bufs[i];
         L.fs[i] = frame_elems[i];
         L.n[i] = n_frames[i];

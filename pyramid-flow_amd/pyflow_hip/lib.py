@@ -67,7 +67,7 @@ class AttnSmallDesc(C.Structure):
                 ("bias", C.c_void_p), ("key_mask", C.c_void_p), ("causal", C.c_int), ("scale", C.c_float)]
 
 
-ABI_VERSION = 6          # PF_ABI_VERSION of include/pyflow_hip.h
+ABI_VERSION = 7          # PF_ABI_VERSION of include/pyflow_hip.h
 GEMM_GATE_RES = 1
 GEMM_OUT_F32 = 2
 GEMM_ACT_QUICK_GELU = 4

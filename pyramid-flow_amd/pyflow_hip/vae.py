@@ -277,8 +277,18 @@ class _TileProgram:
                 b.cur = 0
             self.pool["__owner__"] = self
             return
-        for b in self.bufs.values():
-            b.reset()
+        # a new clip / tile starts: the two cache slots of EVERY buffer read as the causal zero padding again (causal_conv.py:
+        # 128-131) -- one pf_shift_caches launch with n = 0 per 64 buffers (ABI 7; through round 5: one torch fill per buffer,
+        # ~2 500 launches per video)
+        items = [b for b in self.bufs.values() if b.t is not None]
+        lib = L.load()
+        for i0 in range(0, len(items), 64):
+            part = items[i0:i0 + 64]
+            k = len(part)
+            check(lib.pf_shift_caches(C.c_int(k), (C.c_void_p * k)(*[b.t.data_ptr() for b in part]),
+                                      (C.c_longlong * k)(*[b.fs for b in part]), (C.c_int * k)(*([0] * k)), stream()))
+        for b in items:
+            b.cur = 0
 
     def begin_chunk(self):
         self.stats[:max(self._stats_used, 1)].zero_() if self._stats_used else self.stats.zero_()

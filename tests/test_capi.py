@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(so, n)]
     assert not missing, missing
     assert sorted(lib.EXPORTS) == names
-    assert lib.load().pf_version() == lib.ABI_VERSION == 6
+    assert lib.load().pf_version() == lib.ABI_VERSION == 7
 
 
 def test_library_exports_nothing_undeclared():
