@@ -41,3 +41,27 @@ def y4m_bytes(rgb, fps):
     for t in range(T):
         out += [b"FRAME\n", y[t].tobytes(), u[t].tobytes(), v[t].tobytes()]
     return b"".join(out)
+
+
+def diffusers_export_calls(video_frames, output_video_path, fps=10, backend="imageio"):
+    """What `diffusers.utils.export_to_video(video_frames, output_video_path, fps)` -- the call the reference makes at
+    inference_multigpu.py:92,117, app.py:207,260 with a list of 241 PIL images and fps = 24 -- HANDS TO ITS ENCODER, restated
+    from the published source of diffusers 0.30.x (src/diffusers/utils/export_utils.py; the reference pins `diffusers>=0.30.1`,
+    requirements.txt:6; the package itself is not in this image):
+      * a list of numpy arrays is float in [0, 1]: each frame -> (frame * 255).astype(np.uint8)        (export_utils.py)
+      * a list of PIL images: each frame -> np.array(frame)                                               (H x W x 3, RGB)
+      * imageio backend (the default when imageio + imageio-ffmpeg import): `imageio.get_writer(path, fps=fps)` and one
+        `writer.append_data(frame)` per frame, RGB order, in sequence;
+      * legacy OpenCV backend: `cv2.VideoWriter(path, fourcc('mp4v'), fps, (w, h))` and one `write(cv2.cvtColor(frame,
+        cv2.COLOR_RGB2BGR))` per frame.
+    Returns (open_call, [frame arrays in the order and channel order the encoder receives them]).  PARITY UNPINNED against a
+    reference RUN (no encoder exists here): this pins the bytes that reach the encoder, not the encoded file."""
+    frames = list(video_frames)
+    if isinstance(frames[0], np.ndarray):
+        frames = [(f * 255).astype(np.uint8) for f in frames]
+    else:                                                  # PIL.Image.Image
+        frames = [np.array(f) for f in frames]
+    if backend == "imageio":
+        return ("get_writer", output_video_path, dict(fps=fps)), frames
+    h, w, _ = frames[0].shape
+    return ("VideoWriter", output_video_path, dict(fourcc="mp4v", fps=fps, size=(w, h))), [f[:, :, ::-1] for f in frames]

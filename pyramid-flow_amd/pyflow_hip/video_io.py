@@ -30,8 +30,14 @@ def _as_u8_tensor(frames):
     if isinstance(frames, torch.Tensor):
         assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3
         return frames.contiguous()
-    arr = [np.asarray(f.convert("RGB") if hasattr(f, "convert") else f, dtype=np.uint8) for f in frames]
-    return torch.from_numpy(np.stack(arr, 0))
+    def one(f):
+        if hasattr(f, "convert"):                              # PIL image: diffusers takes np.array(frame)
+            return np.asarray(f.convert("RGB"), dtype=np.uint8)
+        f = np.asarray(f)
+        if np.issubdtype(f.dtype, np.floating):                # numpy float frames are in [0, 1]: (frame * 255).astype(uint8),
+            return (f * 255).astype(np.uint8)                  # exactly diffusers' export_to_video
+        return f.astype(np.uint8, copy=False)
+    return torch.from_numpy(np.stack([one(f) for f in frames], 0))
 
 
 class FrameRing:

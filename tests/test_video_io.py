@@ -54,3 +54,65 @@ def test_y4m_device_path_bit_exact(tmp_path, T, H, W, block):
     assert open(path, "rb").read() == y4m_bytes(rgb, 24)
     pa = export_to_video(d, str(tmp_path / "v.avi"), fps=24, block_frames=block)
     assert open(pa, "rb").read() == open(export_to_video(torch.from_numpy(rgb), str(tmp_path / "h.avi")), "rb").read()
+
+
+@pytest.mark.parametrize("backend", ["imageio", "cv2"])
+def test_codec_path_hands_the_encoder_what_diffusers_does(tmp_path, monkeypatch, backend):
+    """(f) 3, round 6: for `.mp4` the product delegates to imageio / OpenCV like diffusers.utils.export_to_video.  With a
+    recording stand-in for the encoder module, the sequence of calls and the frame BYTES it receives equal the restatement of
+    diffusers' pre-encode conversion (oracle/video_oracle.py::diffusers_export_calls) for the three input forms the reference
+    and the product use: a list of PIL images (inference_multigpu.py:92), a list of float arrays in [0, 1], and the uint8
+    [T,H,W,3] tensor of `generate(output_type="uint8")`.  The row stays "parity unpinned": no reference ENCODER exists in this
+    image, so the encoded file itself cannot be compared."""
+    import sys
+    import types
+    from PIL import Image
+    from oracle.video_oracle import diffusers_export_calls
+    from pyflow_hip.video_io import export_to_video
+    rng = np.random.default_rng(5)
+    u8 = rng.integers(0, 256, (4, 16, 32, 3), dtype=np.uint8)
+    calls = []
+
+    class Writer:
+        def __init__(self, *a, **k):
+            calls.append(("open", a, k))
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            calls.append(("close",))
+
+        def append_data(self, fr):
+            calls.append(("frame", np.array(fr, copy=True)))
+
+        def write(self, fr):
+            calls.append(("frame", np.array(fr, copy=True)))
+
+        def release(self):
+            calls.append(("close",))
+    if backend == "imageio":
+        monkeypatch.setitem(sys.modules, "imageio", types.SimpleNamespace(get_writer=lambda path, fps=None: Writer(path, fps=fps)))
+    else:
+        monkeypatch.setitem(sys.modules, "imageio", None)          # `import imageio` raises ImportError
+        monkeypatch.setitem(sys.modules, "cv2", types.SimpleNamespace(
+            VideoWriter=lambda path, fourcc, fps, size: Writer(path, fourcc=fourcc, fps=fps, size=size),
+            VideoWriter_fourcc=lambda *c: "".join(c)))
+    path = str(tmp_path / "v.mp4")
+    forms = {"pil": [Image.fromarray(f) for f in u8], "float": [f.astype(np.float32) / 255.0 for f in u8],
+             "tensor": torch.from_numpy(u8)}
+    for name, frames in forms.items():
+        del calls[:]
+        export_to_video(frames, path, fps=24)
+        ref_in = [f for f in u8] if name == "tensor" else frames       # (the tensor form is the product's own: frames as uint8 arrays)
+        if name == "tensor":
+            open_call, want = diffusers_export_calls([Image.fromarray(f) for f in ref_in], path, fps=24, backend=backend)
+        else:
+            open_call, want = diffusers_export_calls(ref_in, path, fps=24, backend=backend)
+        assert calls[0][0] == "open" and calls[0][1][0] == path and calls[0][2]["fps"] == 24, calls[0]
+        if backend == "cv2":
+            assert calls[0][2]["fourcc"] == "mp4v" and calls[0][2]["size"] == (32, 16)
+        got = [c[1] for c in calls if c[0] == "frame"]
+        assert len(got) == len(want) == 4 and calls[-1] == ("close",)
+        for a, b in zip(got, want):
+            assert a.dtype == np.uint8 and a.shape == b.shape and np.array_equal(a, b), name
