@@ -362,6 +362,18 @@ typedef struct pf_comm pf_comm;
 int pf_comm_unique_id(void* out128);
 int pf_comm_init(pf_comm** out, int rank, int world, const void* unique_id_128);
 int pf_comm_destroy(pf_comm* c);
+/* COPY-ENGINE TRANSPORT (ABI 7).  The v-collectives below move chunks of at most `slot_bytes` WITHOUT kernels once windows are
+ * attached: device-to-device copies between IPC-mapped exchange windows (SDMA over xGMI) ordered by stream memory operations
+ * (hipStreamWriteValue32 / hipStreamWaitValue32) -- a persistent GEMM that owns every CU does not delay them and they take no
+ * CU from it (csrc/comm.hip has the protocol; measured motivation: profiles/r05_comm_overlap_bench.log).  Bootstrap: every
+ * rank calls pf_comm_create_window (allocates its window, returns a 64-byte IPC handle), the host ships all handles to all
+ * ranks, every rank calls pf_comm_attach_windows(handles[world][64]).  Larger chunks keep the RCCL path.
+ * pf_comm_init_local: a communicator without RCCL (own stream + events): usable with windows only.
+ * pf_comm_transport: 0 = RCCL kernels, 1 = windows attached. */
+int pf_comm_init_local(pf_comm** out, int rank, int world);
+int pf_comm_create_window(pf_comm* c, long long slot_bytes, void* handle_out64);
+int pf_comm_attach_windows(pf_comm* c, const void* handles);
+int pf_comm_transport(const pf_comm* c);
 int pf_comm_rank(const pf_comm* c);
 int pf_comm_world(const pf_comm* c);
 int pf_all_to_all_v(pf_comm* c, const void* send, const long long* send_bytes, const long long* send_offs, void* recv,

@@ -76,13 +76,39 @@ int rccl_fail(const char* where, int rc) {
 
 }  // namespace
 
+// COPY-ENGINE TRANSPORT (round 6; pf_comm_create_window / pf_comm_attach_windows).  Round 5 measured on one GPU that an
+// RCCL send / recv KERNEL beside the persistent GEMM hides only ~0.35 of its time (a gemm8p workgroup owns its CU whole: the
+// communication kernel waits for CUs or delays the GEMM), while a copy-engine transfer hides 0.71-0.84
+// (profiles/r05_comm_overlap_bench.log).  With windows attached, pf_all_to_all_v / pf_halo_send_recv / pf_all_gather_v move
+// their chunks WITHOUT kernels: every rank owns one IPC-shared window = `world` slots of `slot` bytes (slot s receives from
+// rank s) + two flag words per peer; rank r copies its chunk for p into p's slot r (hipMemcpyAsync device-to-device between
+// IPC-mapped allocations: SDMA over xGMI), then writes the exchange's sequence number into p's data flag r
+// (hipStreamWriteValue32); p waits for it (hipStreamWaitValue32, >=), copies the slot to where the caller wants it and
+// acknowledges into r's ack flag p -- r's next exchange waits for that acknowledgement before it overwrites the slot.
+// Everything is stream-ordered on the communicator's stream: no host synchronisation, no CU held while waiting.
+// Chunks larger than a slot go through RCCL as before (when the communicator has one).  NOT YET RUN BETWEEN TWO GPUS: the
+// builder's boxes have one; tests/test_sp_gpu.py runs the protocol between two processes that share a GPU.
+struct PeerWin {
+    bool on = false;
+    char* win = nullptr;            // my window: [world][slot] bytes, then data_flag[world], ack_flag[world] (uint32)
+    long long slot = 0;
+    char* peer[64] = {};            // every rank's window as mapped here (peer[rank] = win)
+    unsigned sent[64] = {}, rcvd[64] = {};      // per PAIR: chunks sent to / received from each peer so far (both sides of a pair
+                                                // count the same exchanges, so the sequence numbers agree without any global epoch)
+};
+
 struct pf_comm {
-    rcclComm_t comm;
+    rcclComm_t comm;         // nullptr: a communicator without RCCL (pf_comm_init_local: window transport only)
     int rank, world;
     hipStream_t stream;      // the communicator's own stream
     hipEvent_t ev_in;        // compute stream -> comm stream ordering
     hipEvent_t ev_out;       // comm stream -> waiting stream ordering
+    PeerWin pw;
 };
+
+static unsigned* flag_ptr(char* window, long long slot, int world, int which, int idx) {      // which: 0 = data, 1 = ack
+    return (unsigned*)(window + (long long)world * slot) + which * world + idx;
+}
 
 #define PF_RCCL(call, where)                      \
     do {                                          \
@@ -143,15 +169,135 @@ extern "C" int pf_comm_init(pf_comm** out, int rank, int world, const void* uniq
     return 0;
 }
 
+static void drop_windows(pf_comm* c) {
+    if (!c->pw.win) return;
+    for (int p = 0; p < c->world; ++p)
+        if (p != c->rank && c->pw.peer[p]) hipIpcCloseMemHandle(c->pw.peer[p]);
+    hipFree(c->pw.win);
+    c->pw = PeerWin();
+}
+
 extern "C" int pf_comm_destroy(pf_comm* c) {
     if (!c) return 0;
     hipStreamSynchronize(c->stream);
-    g_api.CommDestroy(c->comm);
+    drop_windows(c);
+    if (c->comm) g_api.CommDestroy(c->comm);
     hipEventDestroy(c->ev_in);
     hipEventDestroy(c->ev_out);
     hipStreamDestroy(c->stream);
     delete c;
     return 0;
+}
+
+// a communicator WITHOUT RCCL: its own stream and events only; collectives work once windows are attached (and then only
+// for chunks that fit a slot).  For hosts / tests whose ranks cannot form an RCCL communicator (several ranks on one GPU).
+extern "C" int pf_comm_init_local(pf_comm** out, int rank, int world) {
+    if (!out || world < 1 || world > 64 || rank < 0 || rank >= world) return pf_set_err("pf_comm_init_local: bad arguments");
+    pf_comm* c = new pf_comm();
+    c->comm = nullptr;
+    c->rank = rank;
+    c->world = world;
+    c->stream = nullptr;
+    c->ev_in = c->ev_out = nullptr;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_out) hipEventDestroy(c->ev_out);
+        if (c->ev_in) hipEventDestroy(c->ev_in);
+        if (c->stream) hipStreamDestroy(c->stream);
+        delete c;
+        return pf_set_err("pf_comm_init_local: stream / event creation failed");
+    }
+    *out = c;
+    return 0;
+}
+
+// step 1 of the window bootstrap: allocate this rank's window (world slots of slot_bytes + flags, zeroed) and return its
+// 64-byte IPC handle; the host ships every rank's handle to every rank (any byte channel), then calls pf_comm_attach_windows
+extern "C" int pf_comm_create_window(pf_comm* c, long long slot_bytes, void* handle_out64) {
+    if (!c || !handle_out64 || slot_bytes <= 0 || (slot_bytes & 255) || c->world > 64) return pf_set_err("pf_comm_create_window: bad arguments (slot_bytes: a multiple of 256)");
+    if (c->pw.win) return pf_set_err("pf_comm_create_window: this communicator has a window");
+    const long long total = (long long)c->world * slot_bytes + 2ll * c->world * 4 + 256;
+    void* w = nullptr;
+    if (hipExtMallocWithFlags(&w, (size_t)total, hipDeviceMallocFinegrained) != hipSuccess || !w) {
+        (void)hipGetLastError();
+        if (hipMalloc(&w, (size_t)total) != hipSuccess) return pf_set_err("pf_comm_create_window: allocation failed");
+    }
+    if (hipMemset(w, 0, (size_t)total) != hipSuccess) { hipFree(w); return pf_set_err("pf_comm_create_window: memset failed"); }
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, w) != hipSuccess) { hipFree(w); return pf_set_err("pf_comm_create_window: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 ?)"); }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    memcpy(handle_out64, &h, 64);
+    c->pw.win = (char*)w;
+    c->pw.slot = slot_bytes;
+    c->pw.peer[c->rank] = (char*)w;
+    return 0;
+}
+
+// step 2: map every other rank's window (handles: world x 64 bytes, entry [rank] ignored) and switch the v-collectives of
+// this communicator to the copy-engine transport for chunks of at most slot_bytes
+extern "C" int pf_comm_attach_windows(pf_comm* c, const void* handles) {
+    if (!c || !handles || !c->pw.win) return pf_set_err("pf_comm_attach_windows: create the window first");
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + 64ll * p, 64);
+        void* ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !ptr) {
+            (void)hipGetLastError();
+            for (int q = 0; q < p; ++q)
+                if (q != c->rank && c->pw.peer[q]) { hipIpcCloseMemHandle(c->pw.peer[q]); c->pw.peer[q] = nullptr; }
+            return pf_set_err("pf_comm_attach_windows: hipIpcOpenMemHandle failed");
+        }
+        c->pw.peer[p] = (char*)ptr;
+    }
+    c->pw.on = true;
+    return 0;
+}
+// 0 = RCCL kernels, 1 = copy engines through attached windows
+extern "C" int pf_comm_transport(const pf_comm* c) { return c && c->pw.on ? 1 : 0; }
+
+// one exchange through the windows: send_* / recv_* as in pf_all_to_all_v.  The pair (me -> p) takes part when to[p] here and
+// from[me] on p: all pairs for the all-to-all / all-gather, the neighbours for the halo pass.  Sequence numbers are per pair.
+static int window_exchange(pf_comm* c, const void* send, const long long* send_bytes, const long long* send_offs, void* recv,
+                           const long long* recv_bytes, const long long* recv_offs, const bool* to, const bool* from,
+                           const char* where) {
+    PeerWin& w = c->pw;
+    const int me = c->rank, P = c->world;
+#define PF_HIP(call)                                                                   \
+    do {                                                                               \
+        if ((call) != hipSuccess) { (void)hipGetLastError(); return pf_set_err(where); } \
+    } while (0)
+    for (int p = 0; p < P; ++p) {
+        if (p == me || !to[p]) continue;
+        // p has copied my previous chunk out of its slot `me` (its acknowledgement lands in MY window)
+        const unsigned e = ++w.sent[p];
+        PF_HIP(hipStreamWaitValue32(c->stream, flag_ptr(w.win, w.slot, P, 1, p), e - 1, hipStreamWaitValueGte, 0xffffffffu));
+        if (send_bytes[p] > 0)
+            PF_HIP(hipMemcpyAsync(w.peer[p] + (long long)me * w.slot, (const char*)send + send_offs[p], (size_t)send_bytes[p],
+                                  hipMemcpyDeviceToDevice, c->stream));
+        PF_HIP(hipStreamWriteValue32(c->stream, flag_ptr(w.peer[p], w.slot, P, 0, me), e, 0));
+    }
+    if (to[me] && send_bytes[me] > 0)
+        PF_HIP(hipMemcpyAsync((char*)recv + recv_offs[me], (const char*)send + send_offs[me], (size_t)send_bytes[me],
+                              hipMemcpyDeviceToDevice, c->stream));
+    for (int p = 0; p < P; ++p) {
+        if (p == me || !from[p]) continue;
+        const unsigned e = ++w.rcvd[p];
+        PF_HIP(hipStreamWaitValue32(c->stream, flag_ptr(w.win, w.slot, P, 0, p), e, hipStreamWaitValueGte, 0xffffffffu));
+        if (recv_bytes[p] > 0)
+            PF_HIP(hipMemcpyAsync((char*)recv + recv_offs[p], w.win + (long long)p * w.slot, (size_t)recv_bytes[p],
+                                  hipMemcpyDeviceToDevice, c->stream));
+        PF_HIP(hipStreamWriteValue32(c->stream, flag_ptr(w.peer[p], w.slot, P, 1, me), e, 0));
+    }
+#undef PF_HIP
+    return 0;
+}
+static bool fits_windows(const pf_comm* c, const long long* a, const long long* b) {
+    if (!c->pw.on) return false;
+    for (int p = 0; p < c->world; ++p)
+        if ((a && a[p] > c->pw.slot) || (b && b[p] > c->pw.slot)) return false;
+    return true;
 }
 
 extern "C" int pf_comm_rank(const pf_comm* c) { return c ? c->rank : -1; }
@@ -162,6 +308,12 @@ extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* se
                                void* recv, const long long* recv_bytes, const long long* recv_offs, hipStream_t compute) {
     if (!c || !send_bytes || !send_offs || !recv_bytes || !recv_offs) return pf_set_err("pf_all_to_all_v: null argument");
     if (order_after(c, compute)) return -1;
+    if (fits_windows(c, send_bytes, recv_bytes)) {
+        bool all[64];
+        for (int p = 0; p < c->world; ++p) all[p] = true;
+        return window_exchange(c, send, send_bytes, send_offs, recv, recv_bytes, recv_offs, all, all, "pf_all_to_all_v: window transport failed");
+    }
+    if (!c->comm) return pf_set_err("pf_all_to_all_v: a chunk exceeds the window slot and this communicator has no RCCL");
     PF_RCCL(g_api.GroupStart(), "pf_all_to_all_v");
     for (int p = 0; p < c->world; ++p) {
         if (send_bytes[p] > 0)
@@ -177,6 +329,19 @@ extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* se
 extern "C" int pf_halo_send_recv(pf_comm* c, const void* send, void* recv, long long bytes, hipStream_t compute) {
     if (!c || bytes < 0) return pf_set_err("pf_halo_send_recv: bad arguments");
     if (order_after(c, compute)) return -1;
+    if (c->pw.on && bytes <= c->pw.slot) {
+        long long sb[64], rb[64], zo[64];
+        bool to[64], from[64];
+        for (int p = 0; p < c->world; ++p) {
+            to[p] = p == c->rank + 1;
+            from[p] = p == c->rank - 1;
+            sb[p] = to[p] ? bytes : 0;
+            rb[p] = from[p] ? bytes : 0;
+            zo[p] = 0;
+        }
+        return window_exchange(c, send, sb, zo, recv, rb, zo, to, from, "pf_halo_send_recv: window transport failed");
+    }
+    if (!c->comm) return pf_set_err("pf_halo_send_recv: the halo exceeds the window slot and this communicator has no RCCL");
     PF_RCCL(g_api.GroupStart(), "pf_halo_send_recv");
     if (c->rank + 1 < c->world && bytes > 0)
         PF_RCCL_IN_GROUP(g_api.Send(send, (size_t)bytes, RCCL_UINT8, c->rank + 1, c->comm, c->stream), "pf_halo_send_recv");
@@ -191,6 +356,13 @@ extern "C" int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const l
                                hipStream_t compute) {
     if (!c || !bytes || !offs) return pf_set_err("pf_all_gather_v: null argument");
     if (order_after(c, compute)) return -1;
+    if (fits_windows(c, bytes, nullptr)) {
+        long long sb[64], zo[64];
+        bool all[64];
+        for (int p = 0; p < c->world; ++p) { sb[p] = bytes[c->rank]; zo[p] = 0; all[p] = true; }
+        return window_exchange(c, send, sb, zo, recv, bytes, offs, all, all, "pf_all_gather_v: window transport failed");
+    }
+    if (!c->comm) return pf_set_err("pf_all_gather_v: a part exceeds the window slot and this communicator has no RCCL");
     PF_RCCL(g_api.GroupStart(), "pf_all_gather_v");
     for (int p = 0; p < c->world; ++p) {
         if (bytes[c->rank] > 0)
@@ -204,6 +376,7 @@ extern "C" int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const l
 
 extern "C" int pf_all_reduce_sum_f32(pf_comm* c, float* buf, long long count, hipStream_t compute) {
     if (!c || !buf || count < 0) return pf_set_err("pf_all_reduce_sum_f32: bad arguments");
+    if (!c->comm) return pf_set_err("pf_all_reduce_sum_f32: this communicator has no RCCL (pf_comm_init_local)");
     if (order_after(c, compute)) return -1;
     PF_RCCL(g_api.AllReduce(buf, buf, (size_t)count, RCCL_FLOAT32, RCCL_SUM, c->comm, c->stream), "pf_all_reduce_sum_f32");
     return 0;
@@ -211,6 +384,7 @@ extern "C" int pf_all_reduce_sum_f32(pf_comm* c, float* buf, long long count, hi
 
 extern "C" int pf_broadcast_bytes(pf_comm* c, void* buf, long long bytes, int root, hipStream_t compute) {
     if (!c || !buf || bytes < 0 || root < 0 || root >= c->world) return pf_set_err("pf_broadcast_bytes: bad arguments");
+    if (!c->comm) return pf_set_err("pf_broadcast_bytes: this communicator has no RCCL (pf_comm_init_local)");
     if (order_after(c, compute)) return -1;
     PF_RCCL(g_api.Broadcast(buf, buf, (size_t)bytes, RCCL_UINT8, root, c->comm, c->stream), "pf_broadcast_bytes");
     return 0;

@@ -73,13 +73,33 @@ class NativeComm:
     recordable = True          # all_to_all / wait have launch-list entries (pf_cmdlist_all_to_all_v / pf_cmdlist_comm_wait)
 
     def __init__(self, rank, world, unique_id):
+        """unique_id = None: a communicator WITHOUT RCCL (pf_comm_init_local) -- usable once windows are attached
+        (attach_windows: the copy-engine transport), for chunks that fit a window slot"""
         lib = L.load()
         self._lib = lib
         self.rank, self.world = rank, world
         self.group = None
         h = C.c_void_p()
-        check(lib.pf_comm_init(C.byref(h), C.c_int(rank), C.c_int(world), C.c_char_p(unique_id)))
+        if unique_id is None:
+            check(lib.pf_comm_init_local(C.byref(h), C.c_int(rank), C.c_int(world)))
+        else:
+            check(lib.pf_comm_init(C.byref(h), C.c_int(rank), C.c_int(world), C.c_char_p(unique_id)))
         self._h = h
+
+    def attach_windows(self, slot_bytes, gather_handles):
+        """switch the v-collectives (all_to_all, shift / halo pass, all_gather_v, send / recv) to the COPY-ENGINE transport
+        (csrc/comm.hip: IPC-mapped exchange windows, device-to-device copies, stream-ordered flags; no kernel, no CU) for
+        chunks of at most `slot_bytes` (a multiple of 256).  gather_handles(my64: bytes) -> [bytes] * world: the host's byte
+        channel (e.g. a torch.distributed all_gather_object, or files)."""
+        buf = (C.c_char * 64)()
+        check(self._lib.pf_comm_create_window(self._h, C.c_longlong(slot_bytes), buf))
+        handles = gather_handles(bytes(buf))
+        assert len(handles) == self.world and all(len(h_) == 64 for h_ in handles)
+        check(self._lib.pf_comm_attach_windows(self._h, C.c_char_p(b"".join(handles))))
+        self.transport = "windows"
+        return self
+
+    transport = "rccl"
 
     def close(self):
         if self._h:

@@ -75,7 +75,7 @@ GEMM_ACT_GELU_ERF = 8
 
 # every symbol include/pyflow_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "pf_last_error", "pf_version", "pf_struct_size", "pf_gemm_bf16", "pf_gemm_set_policy", "pf_gemm_which", "pf_gemm_which_desc", "pf_gemm_workgroups", "pf_gemm_workspace_bytes", "pf_conv3d_bf16", "pf_conv3d_fuses_gn_stats", "pf_conv3d_which", "pf_attention_bf16", "pf_attention_workspace_bytes", "pf_attention_which", "pf_v_transpose",
+    "pf_last_error", "pf_version", "pf_comm_init_local", "pf_comm_create_window", "pf_comm_attach_windows", "pf_comm_transport", "pf_struct_size", "pf_gemm_bf16", "pf_gemm_set_policy", "pf_gemm_which", "pf_gemm_which_desc", "pf_gemm_workgroups", "pf_gemm_workspace_bytes", "pf_conv3d_bf16", "pf_conv3d_fuses_gn_stats", "pf_conv3d_which", "pf_attention_bf16", "pf_attention_workspace_bytes", "pf_attention_which", "pf_v_transpose",
     "pf_ln_modulate", "pf_qk_norm_rope", "pf_gemv_f32", "pf_timestep_embed", "pf_patchify", "pf_cfg_euler_step",
     "pf_copy_rows", "pf_sp_relayout", "pf_renoise_upsample", "pf_avgpool2",
     "pf_gn_stats", "pf_gn_apply", "pf_softmax_rows", "pf_shift_caches", "pf_latent_to_nhwc", "pf_blend_tiles", "pf_nhwc_to_planar_f32", "pf_to_uint8",

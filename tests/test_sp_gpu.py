@@ -168,3 +168,14 @@ def test_native_communicator_on_one_rank():
                        stderr=subprocess.STDOUT, timeout=300)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     print(p.stdout.decode()[-200:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_copy_engine_window_transport(tmp_path, world):
+    """round 6: the second transport of the C-ABI communicator -- chunks move as device-to-device copies between IPC-mapped
+    exchange windows, ordered by stream memory operations (no RCCL kernel that would have to share CUs with the persistent
+    GEMM: profiles/r05_comm_overlap_bench.log).  Uneven all-to-all five times over (slot reuse behind the acknowledgement
+    flags), the halo pass between them (pairs that do not take part keep their sequence numbers), all-gather, send / recv, and
+    the clean error for a chunk with no route.  Rank processes share the one GPU of the test box: what is NOT covered is a
+    second device (xGMI, peer access) -- DESIGN.md section 5 says so."""
+    _launch(world, "window_comm_worker.py", [], tmp_path)
