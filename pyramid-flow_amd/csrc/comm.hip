@@ -278,7 +278,7 @@ static int window_exchange(pf_comm* c, const void* send, const long long* send_b
                                   hipMemcpyDeviceToDevice, c->stream));
         PF_HIP(hipStreamWriteValue32(c->stream, flag_ptr(w.peer[p], w.slot, P, 0, me), e, 0));
     }
-    if (to[me] && send_bytes[me] > 0)
+    if (send_bytes[me] > 0)
         PF_HIP(hipMemcpyAsync((char*)recv + recv_offs[me], (const char*)send + send_offs[me], (size_t)send_bytes[me],
                               hipMemcpyDeviceToDevice, c->stream));
     for (int p = 0; p < P; ++p) {
@@ -293,13 +293,6 @@ static int window_exchange(pf_comm* c, const void* send, const long long* send_b
 #undef PF_HIP
     return 0;
 }
-static bool fits_windows(const pf_comm* c, const long long* a, const long long* b) {
-    if (!c->pw.on) return false;
-    for (int p = 0; p < c->world; ++p)
-        if ((a && a[p] > c->pw.slot) || (b && b[p] > c->pw.slot)) return false;
-    return true;
-}
-
 extern "C" int pf_comm_rank(const pf_comm* c) { return c ? c->rank : -1; }
 extern "C" int pf_comm_world(const pf_comm* c) { return c ? c->world : -1; }
 
@@ -308,17 +301,24 @@ extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* se
                                void* recv, const long long* recv_bytes, const long long* recv_offs, hipStream_t compute) {
     if (!c || !send_bytes || !send_offs || !recv_bytes || !recv_offs) return pf_set_err("pf_all_to_all_v: null argument");
     if (order_after(c, compute)) return -1;
-    if (fits_windows(c, send_bytes, recv_bytes)) {
-        bool all[64];
-        for (int p = 0; p < c->world; ++p) all[p] = true;
-        return window_exchange(c, send, send_bytes, send_offs, recv, recv_bytes, recv_offs, all, all, "pf_all_to_all_v: window transport failed");
+    // the route is decided PER PAIR, on a number both ends of the pair know (what r sends to p is what p receives from r):
+    // chunks of at most a window slot travel through the windows, larger ones through RCCL -- no rank can end up waiting on a
+    // transport its peer did not take
+    bool via_win_to[64], via_win_from[64], rest = false;
+    for (int p = 0; p < c->world; ++p) {
+        via_win_to[p] = c->pw.on && (p == c->rank || send_bytes[p] <= c->pw.slot);
+        via_win_from[p] = c->pw.on && (p == c->rank || recv_bytes[p] <= c->pw.slot);
+        rest = rest || (!via_win_to[p] && send_bytes[p] > 0) || (!via_win_from[p] && recv_bytes[p] > 0);
     }
+    if (c->pw.on && window_exchange(c, send, send_bytes, send_offs, recv, recv_bytes, recv_offs, via_win_to, via_win_from,
+                                    "pf_all_to_all_v: window transport failed")) return -1;
+    if (!rest) return 0;
     if (!c->comm) return pf_set_err("pf_all_to_all_v: a chunk exceeds the window slot and this communicator has no RCCL");
     PF_RCCL(g_api.GroupStart(), "pf_all_to_all_v");
     for (int p = 0; p < c->world; ++p) {
-        if (send_bytes[p] > 0)
+        if (send_bytes[p] > 0 && !via_win_to[p])
             PF_RCCL_IN_GROUP(g_api.Send((const char*)send + send_offs[p], (size_t)send_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
-        if (recv_bytes[p] > 0)
+        if (recv_bytes[p] > 0 && !via_win_from[p])
             PF_RCCL_IN_GROUP(g_api.Recv((char*)recv + recv_offs[p], (size_t)recv_bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_to_all_v");
     }
     PF_RCCL(g_api.GroupEnd(), "pf_all_to_all_v");
@@ -356,18 +356,24 @@ extern "C" int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const l
                                hipStream_t compute) {
     if (!c || !bytes || !offs) return pf_set_err("pf_all_gather_v: null argument");
     if (order_after(c, compute)) return -1;
-    if (fits_windows(c, bytes, nullptr)) {
-        long long sb[64], zo[64];
-        bool all[64];
-        for (int p = 0; p < c->world; ++p) { sb[p] = bytes[c->rank]; zo[p] = 0; all[p] = true; }
-        return window_exchange(c, send, sb, zo, recv, bytes, offs, all, all, "pf_all_gather_v: window transport failed");
+    // per part: rank r's part reaches everyone through the windows when it fits a slot (every rank knows every part's size)
+    bool via_to[64], via_from[64], rest = false;
+    long long sb[64], zo[64];
+    for (int p = 0; p < c->world; ++p) {
+        sb[p] = bytes[c->rank];
+        zo[p] = 0;
+        via_to[p] = c->pw.on && (p == c->rank || bytes[c->rank] <= c->pw.slot);
+        via_from[p] = c->pw.on && (p == c->rank || bytes[p] <= c->pw.slot);
+        rest = rest || (!via_to[p] && bytes[c->rank] > 0) || (!via_from[p] && bytes[p] > 0);
     }
+    if (c->pw.on && window_exchange(c, send, sb, zo, recv, bytes, offs, via_to, via_from, "pf_all_gather_v: window transport failed")) return -1;
+    if (!rest) return 0;
     if (!c->comm) return pf_set_err("pf_all_gather_v: a part exceeds the window slot and this communicator has no RCCL");
     PF_RCCL(g_api.GroupStart(), "pf_all_gather_v");
     for (int p = 0; p < c->world; ++p) {
-        if (bytes[c->rank] > 0)
+        if (bytes[c->rank] > 0 && !via_to[p])
             PF_RCCL_IN_GROUP(g_api.Send(send, (size_t)bytes[c->rank], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
-        if (bytes[p] > 0)
+        if (bytes[p] > 0 && !via_from[p])
             PF_RCCL_IN_GROUP(g_api.Recv((char*)recv + offs[p], (size_t)bytes[p], RCCL_UINT8, p, c->comm, c->stream), "pf_all_gather_v");
     }
     PF_RCCL(g_api.GroupEnd(), "pf_all_gather_v");

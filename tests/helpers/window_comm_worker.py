@@ -25,6 +25,7 @@ def main():
     c = NativeComm(rank, world, None).attach_windows(1 << 20, gather)
     assert c._lib.pf_comm_transport(c._h) == 1 and c.transport == "windows"
     ok = True
+    print(f"rank {rank}: windows attached", flush=True)
     for it in range(5):                       # repeated exchanges reuse the slots: the acknowledgement protocol
         # uneven all-to-all: rank r sends (p + 1) * 100 + it elements of value 1000 r + p + it / 16 to rank p
         send_spl = [(p + 1) * 100 + it for p in range(world)]
@@ -41,6 +42,7 @@ def main():
         c.shift(torch.full((64,), float(10 * rank + it), device="cuda"), keep)
         want = -7.0 if rank == 0 else float(10 * (rank - 1) + it)
         ok = ok and bool((keep.cpu() == want).all())
+        print(f"rank {rank}: round {it} ok={ok}", flush=True)
     counts = [10 + 3 * p for p in range(world)]
     g = torch.zeros(sum(counts), device="cuda")
     c.all_gather_v(torch.full((counts[rank],), float(rank + 1), device="cuda"), g, counts)
@@ -53,14 +55,25 @@ def main():
     else:
         c.send(torch.full((33,), float(rank), device="cuda"), 0)
     torch.cuda.synchronize()
-    # a chunk larger than a slot has no route on a communicator without RCCL: a clean error, not a hang
+    # a chunk larger than a slot has no route on a communicator without RCCL: BOTH ends of that pair (0 -> 1) get a clean
+    # error, the pairs that fit still complete (nobody is left waiting), and the next exchange works
+    n_big = (1 << 20) + 512
+    big = torch.zeros(n_big, dtype=torch.uint8, device="cuda")
+    ss = [0] * world
+    rs = [0] * world
+    if rank == 0:
+        ss[1] = n_big
+    if rank == 1:
+        rs[0] = n_big
     try:
-        big = torch.zeros((1 << 20) + 512, dtype=torch.uint8, device="cuda")
-        c.all_to_all(big.clone(), big, [big.numel()] + [0] * (world - 1) if rank == 0 else [0] * world,
-                     [big.numel()] + [0] * (world - 1) if rank == 0 else [0] * world)
-        ok = ok and rank != 0
+        c.all_to_all(big.clone(), big, rs, ss)
+        ok = ok and rank not in (0, 1)
     except RuntimeError as e:
-        ok = ok and "window slot" in str(e)
+        ok = ok and rank in (0, 1) and "window slot" in str(e)
+    t_in = torch.full((8 * world,), float(rank), device="cuda")
+    t_out = torch.zeros(8 * world, device="cuda")
+    c.all_to_all(t_out, t_in, [8] * world, [8] * world)
+    ok = ok and torch.equal(t_out.cpu(), torch.arange(world, dtype=torch.float32).repeat_interleave(8))
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
     dist.barrier()
