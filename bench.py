@@ -357,6 +357,10 @@ def main():
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
                     help="N > 1, sp: communicator -- auto = the C-ABI RCCL communicator (pf_comm_*) when its self-test passes on "
                          "every rank, else torch.distributed")
+    ap.add_argument("--comm-windows", type=int, default=0, metavar="MIB",
+                    help="N > 1, --comm native / auto: attach exchange windows with slots of MIB MiB to the C-ABI communicator: chunks "
+                         "up to that size travel by the COPY ENGINES (IPC-mapped windows, stream memory ops) instead of RCCL "
+                         "kernels.  0 (default) = RCCL only: the window transport has not run between two GPUs yet (DESIGN.md 5)")
     ap.add_argument("--gemm-policy", type=int, action="append", default=[],
                     help="A/B switch: pf_gemm_set_policy(value) before the model is built (e.g. -5 = no LDS-halo conv, -4 = no "
                          "tail split); repeatable.  Not for the headline line")
@@ -399,7 +403,8 @@ def main():
             def try_comm(native):
                 """build the communicator and run every collective of the path once with known values"""
                 try:
-                    c = sp_mod.init_sequence_parallel_group(sp_group_size=world, native=native, guidance_parallel=guidance)
+                    c = sp_mod.init_sequence_parallel_group(sp_group_size=world, native=native, guidance_parallel=guidance,
+                                                            window_mib=args.comm_windows if native else 0)
                     c.selftest(device)
                     return c, True
                 except Exception as e:          # noqa: BLE001
@@ -752,7 +757,9 @@ def main():
         backend = torch.distributed.get_backend()
         res["launcher"] = "bench.py self-launch" if os.environ.get("PF_BENCH_LAUNCHER") == "self" else "external (torchrun)"
         res["rccl_ranks"] = world if backend == "nccl" else 0
-        res["communicator"] = ("pf_comm (C-ABI RCCL communicator)" if getattr(comm_used, "backend", "") == "pf_comm" else
+        res["communicator"] = (("pf_comm (C-ABI RCCL communicator" + (f" + copy-engine windows of {args.comm_windows} MiB)"
+                                                                     if getattr(comm_used, "transport", "") == "windows" else ")"))
+                               if getattr(comm_used, "backend", "") == "pf_comm" else
                                f"torch.distributed ({backend}" + (" = RCCL)" if backend == "nccl" else
                                "; ranks share GPUs, transport through the host: PLUMBING ONLY, not a measurement)"))
         res["requested_parallelism"] = args.parallelism

@@ -284,11 +284,12 @@ def pair_gather(comm, mine, out):
     return out
 
 
-def init_sequence_parallel_group(args=None, sp_group_size=None, native=False, guidance_parallel=False):
+def init_sequence_parallel_group(args=None, sp_group_size=None, native=False, guidance_parallel=False, window_mib=0):
     """trainer_misc/sp_utils.py:21-47: consecutive-rank groups of `sp_group_size` (default: the whole world) over the
     first `args.sp_proc_num` processes (-1 / absent = all).  A process outside every group stays un-initialised.
     native=True (whole-world group only): the collectives go through the C-ABI communicator (pf_comm_*, RCCL driven
-    directly on its own HIP stream) instead of torch.distributed; torch.distributed is used once, to ship the id."""
+    directly on its own HIP stream) instead of torch.distributed; torch.distributed is used once, to ship the id.
+    window_mib > 0 (native only): attach exchange windows of that slot size -- the copy-engine transport."""
     global _SP, _SP_PROC_NUM, _GUIDANCE_PARALLEL
     world = dist.get_world_size()
     # guidance_parallel (a world of two only; not a reference option): the two ranks split the classifier-free-guidance pair
@@ -299,6 +300,14 @@ def init_sequence_parallel_group(args=None, sp_group_size=None, native=False, gu
         rank = dist.get_rank()
         _SP_PROC_NUM = world
         _SP = NativeComm(rank, world, exchange_unique_id(rank, world))
+        if window_mib > 0:
+            # the copy-engine transport for chunks of at most window_mib MiB (csrc/comm.hip: IPC-mapped exchange windows, no
+            # communication kernel beside the persistent GEMM); torch.distributed ships the 64-byte IPC handles, once
+            def gather(mine):
+                out = [None] * world
+                dist.all_gather_object(out, mine)
+                return out
+            _SP.attach_windows(window_mib << 20, gather)
         return _SP
     size = sp_group_size or getattr(args, "sp_group_size", None) or world
     proc = getattr(args, "sp_proc_num", -1) if args is not None else -1
