@@ -303,6 +303,8 @@ def self_launch(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.device_count() < n:
         env.setdefault("PF_DIST_BACKEND", "gloo")
+        # ranks sharing one box's cores (plumbing runs): without a cap every rank's OpenMP pool spins on all of them
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     def die_with_launcher():
         # a launcher that is killed outright (a test harness's timeout, the driver's clock) must not leave rank processes
         # behind on the GPU: the kernel delivers SIGKILL to every rank when this process goes away (PR_SET_PDEATHSIG = 1)

@@ -138,8 +138,9 @@ def test_second_video_replays_the_first_videos_graphs_bit_identically():
     assert pipe.dit.list_stats["records"] == s1["records"] and not torch.equal(other, first)
     pipe.dit.launch_mode = "eager"
     assert torch.equal(video(), first)
-    # the cache is bounded: least recently used plans leave first
+    # the cache is bounded: inserting the plans of ANOTHER geometry evicts the least recently used ones
     pipe.plan_cache_size = 4
     pipe.dit.launch_mode = "graph"
-    video()
+    pipe.generate(prompt_embeds=embeds, height=64, width=64, temp=2, num_inference_steps=[1, 1, 1], video_num_inference_steps=[1, 1, 1],
+                  guidance_scale=7.0, video_guidance_scale=5.0, generator=torch.Generator().manual_seed(3), output_type="latent")
     assert len(pipe._plans) == 4

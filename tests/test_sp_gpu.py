@@ -98,6 +98,7 @@ def _launch(world, script, args, tmp_path):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // world)))       # the ranks share this box's cores
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", script), str(out)] + [str(a) for a in args],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
