@@ -306,8 +306,10 @@ extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* se
     // transport its peer did not take
     bool via_win_to[64], via_win_from[64], rest = false;
     for (int p = 0; p < c->world; ++p) {
-        via_win_to[p] = c->pw.on && (p == c->rank || send_bytes[p] <= c->pw.slot);
-        via_win_from[p] = c->pw.on && (p == c->rank || recv_bytes[p] <= c->pw.slot);
+        // (a direction that carries nothing is skipped altogether, as the RCCL path skips it: the two ends of a pair must
+        //  count the same exchanges -- a send / recv pair is an all-to-all in which only one pair takes part)
+        via_win_to[p] = c->pw.on && (p == c->rank || (send_bytes[p] > 0 && send_bytes[p] <= c->pw.slot));
+        via_win_from[p] = c->pw.on && (p == c->rank || (recv_bytes[p] > 0 && recv_bytes[p] <= c->pw.slot));
         rest = rest || (!via_win_to[p] && send_bytes[p] > 0) || (!via_win_from[p] && recv_bytes[p] > 0);
     }
     if (c->pw.on && window_exchange(c, send, send_bytes, send_offs, recv, recv_bytes, recv_offs, via_win_to, via_win_from,
@@ -329,7 +331,7 @@ extern "C" int pf_all_to_all_v(pf_comm* c, const void* send, const long long* se
 extern "C" int pf_halo_send_recv(pf_comm* c, const void* send, void* recv, long long bytes, hipStream_t compute) {
     if (!c || bytes < 0) return pf_set_err("pf_halo_send_recv: bad arguments");
     if (order_after(c, compute)) return -1;
-    if (c->pw.on && bytes <= c->pw.slot) {
+    if (c->pw.on && bytes > 0 && bytes <= c->pw.slot) {
         long long sb[64], rb[64], zo[64];
         bool to[64], from[64];
         for (int p = 0; p < c->world; ++p) {
@@ -362,8 +364,8 @@ extern "C" int pf_all_gather_v(pf_comm* c, const void* send, void* recv, const l
     for (int p = 0; p < c->world; ++p) {
         sb[p] = bytes[c->rank];
         zo[p] = 0;
-        via_to[p] = c->pw.on && (p == c->rank || bytes[c->rank] <= c->pw.slot);
-        via_from[p] = c->pw.on && (p == c->rank || bytes[p] <= c->pw.slot);
+        via_to[p] = c->pw.on && (p == c->rank || (bytes[c->rank] > 0 && bytes[c->rank] <= c->pw.slot));
+        via_from[p] = c->pw.on && (p == c->rank || (bytes[p] > 0 && bytes[p] <= c->pw.slot));
         rest = rest || (!via_to[p] && bytes[c->rank] > 0) || (!via_from[p] && bytes[p] > 0);
     }
     if (c->pw.on && window_exchange(c, send, sb, zo, recv, bytes, offs, via_to, via_from, "pf_all_gather_v: window transport failed")) return -1;

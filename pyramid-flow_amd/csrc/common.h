@@ -72,6 +72,27 @@ PF_DEVICE float gelu_tanh(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 
+// the same function on 8 values, two per instruction: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 do the five non-transcendental
+// operations of a pair at once (3 + 1 + 1 packed instructions instead of 10; exp2 / rcp stay per element) -- per element the
+// same IEEE operations in the same order as gelu_tanh(): the same bits.  The GELU flavour of the persistent GEMM spends
+// 10 k cycles of a tile boundary in this arithmetic (profiles/r06_gemm8p_stamps.log).
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+PF_DEVICE void gelu_tanh8(float* v) {
+    const float k1 = -2.0f * 1.4426950408889634f * 0.7978845608028654f * 0.044715f, k0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const pf_f32x2 x = {v[2 * i], v[2 * i + 1]};
+        const pf_f32x2 x2 = x * x;
+        const pf_f32x2 t = x * __builtin_elementwise_fma(x2, (pf_f32x2){k1, k1}, (pf_f32x2){k0, k0});
+        pf_f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        e = (pf_f32x2){1.0f, 1.0f} + e;
+        const pf_f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+        const pf_f32x2 o = x * r;
+        v[2 * i] = o[0];
+        v[2 * i + 1] = o[1];
+    }
+}
+
 // CLIP text towers: quick_gelu = x * sigmoid(1.702 x) (CLIP-L), exact erf GELU (CLIP-G); transformers activations.py
 PF_DEVICE float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 PF_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }

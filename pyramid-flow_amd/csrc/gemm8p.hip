@@ -544,10 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                         }
                     }
                     if (E_ACT) {
-                        if (do_act) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
-                        }
+                        if (do_act) gelu_tanh8(v);
                     }
                     if (E_RES) {
                         float rv[8];

@@ -104,7 +104,7 @@ def _launch(world, script, args, tmp_path):
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=900)
+            o, _ = p.communicate(timeout=300)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
