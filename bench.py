@@ -41,8 +41,8 @@ WORKLOADS = {
 }
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # HBM3E (same guide)
-PMC_PROFILE = "r05_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the DiT kernels' `traffic` fields are replayed from
-PMC_PROFILE_VAE = "r05_pmc_vae_tile.json"      # ... and the VAE kernels' (one tile-chunk window at the timed launch shapes)
+PMC_PROFILE = "r06_pmc_forward_maxL.json"      # committed rocprofv3 --pmc passes the DiT kernels' `traffic` fields are replayed from
+PMC_PROFILE_VAE = "r06_pmc_vae_tile.json"      # ... and the VAE kernels' (one tile-chunk window at the timed launch shapes)
 
 
 def build_pipeline(device, tiny=False, mmdit=False, stages=None):

@@ -24,8 +24,10 @@ for k, d in kern.items():
         h, mi = d["TCC_HIT_sum"][1], d["TCC_MISS_sum"][1]
         e["l2_hit"] = h / max(h + mi, 1.0)
     out[k] = e
+target = ("tools/vae_only.py (one 256 x 256-pixel tile, chunk windows of the tiled decode at the released channel widths)"
+          if "vae" in src.lower() else "tools/forward_only.py (2 full-width miniFLUX forwards at L=15488, B=2)")
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum in separate passes over "
-                   "tools/forward_only.py (2 full-width miniFLUX forwards at L=15488, B=2). hbm_bytes_per_launch = "
+                   + target + ". hbm_bytes_per_launch = "
                    "(2*FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
                    "coalesced reads); counted at the L2<->fabric interface, Infinity-Cache hits included.",
            "kernels": out}, open(dst, "w"), indent=1)
