@@ -172,13 +172,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
         }
     };
     auto mfmas = [&]() {
+#ifdef PF_HALO_PRIO_FLIPS          // (lab: the per-slot priority flips of rounds 4-5)
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int f = 0; f < 8; ++f)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[f], acc[f][j], 0, 0, 0);
+#ifdef PF_HALO_PRIO_FLIPS
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- prologue: halo of stage 0, filter slices of steps 0..2; then: halo 0 + slice 0 landed
@@ -190,6 +194,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo128_kernel(const HArgs p) {
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     BAR();
     if (SKEW && grp == 1) BAR();                     // group 1 runs one barrier behind
+#ifndef PF_HALO_PRIO_FLIPS
+    // static priority for the second-dispatched wave group, no per-slot flips (as gemm8p.hip since round 6)
+    if (SKEW && grp == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // ---- main loop.  Slot structure per step and group: [R: issue DMA, read fragments] barrier [M: 32 MFMAs] barrier.
     // SKEW: group 0's R(s) coincides with group 1's M(s - 1).  The counted wait for the NEXT step's operands sits at the
