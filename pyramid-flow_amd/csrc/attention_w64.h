@@ -88,7 +88,50 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     const int nq_run = nq2 - qt0;
     const int S = SPLIT ? p.nsplit : 1;
     const int nwg = nq_run * S * p.H * p.B;
-    const int t = xcd_remap(blockIdx.x, nwg);
+    int t = xcd_remap(blockIdx.x, nwg);
+#ifndef PF_ATTN_NO_LIGHT_LAST
+    // LIGHT QUERY TILES LAST (round 6).  The order was (batch, head)-major with every head's query tiles heaviest first: an XCD's
+    // 64 workgroup slots end a launch on the LAST head's tiles, whose heaviest workgroups started late and run twice the
+    // average -- a tail of ~half a heavy workgroup (9 % of the launch at L = 15 488, more at shorter sequences).  Now every XCD
+    // walks the HEAVY tiles of its heads first (same order: one head's K / V at a time in its L2) and the LIGHT tiles of all
+    // its heads at the end (the history frames' rows: they see less than half of the keys, i.e. only the first part of K / V):
+    // the launch ends on short workgroups that fill the slots while the last heavy ones finish.  A bijection of the same
+    // workgroup list: nothing else changes.  "Light" = a tile group whose key range ends below half of the longest one
+    // (batch entry 0's table, so that every workgroup derives the same permutation).
+    if (S == 1 && !COMBINE) {
+        int kmax = 0;
+        for (int i = lane; i < p.nqt; i += 64) kmax = max(kmax, p.tile_kv_end[i]);
+#pragma unroll
+        for (int o_ = 1; o_ < 64; o_ <<= 1) kmax = max(kmax, __shfl_xor(kmax, o_));
+        int nheavy = 0;                                        // tile groups [qt0, nq2) that are not light
+        for (int g0 = qt0 + lane; g0 < nq2; g0 += 64) {
+            int kv = 0;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (NT * g0 + i < p.nqt) kv = max(kv, p.tile_kv_end[NT * g0 + i]);
+            nheavy += (2 * kv >= kmax) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o_ = 1; o_ < 64; o_ <<= 1) nheavy += __shfl_xor(nheavy, o_);
+        nheavy = __builtin_amdgcn_readfirstlane(nheavy);
+        const int nh = nheavy, nl = nq_run - nheavy;
+        if (nl > 0 && nh > 0) {
+            // this XCD's chunk [c0, c0 + len) of the linear order u = bh * nq_run + qrank; position i inside it
+            const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+            const int c0 = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+            const int c1 = c0 + q8 + (xcd < r8 ? 1 : 0);
+            auto heavy_below = [&](int c) { return (c / nq_run) * nh + min(c % nq_run, nh); };       // heavy u in [0, c)
+            const int h0 = heavy_below(c0), hn = heavy_below(c1) - h0;
+            if (i < hn) {
+                const int k = h0 + i;
+                t = (k / nh) * nq_run + (k % nh);
+            } else {
+                const int k = (c0 - h0) + (i - hn);                                                       // light u in [0, c0) + ...
+                t = (k / nl) * nq_run + nh + (k % nl);
+            }
+        }
+    }
+#endif
     const int bh = t / (nq_run * S);
     const int rem_ = t - bh * (nq_run * S);
     const int qrank = rem_ / S, part = rem_ - qrank * S;
