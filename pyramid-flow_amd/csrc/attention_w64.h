@@ -98,7 +98,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
     // the launch ends on short workgroups that fill the slots while the last heavy ones finish.  A bijection of the same
     // workgroup list: nothing else changes.  "Light" = a tile group whose key range ends below half of the longest one
     // (batch entry 0's table, so that every workgroup derives the same permutation).
-    if (S == 1 && !COMBINE) {
+    // (not in the KV-split form: its COMBINE launch flags workgroups by block index for the FIXUP launch, and both must map
+    //  a block index to the same tile; those launches are at most 1.25 rounds of the chip anyway)
+    if (S == 1 && !COMBINE && p.nsplit <= 1) {
         int kmax = 0;
         for (int i = lane; i < p.nqt; i += 64) kmax = max(kmax, p.tile_kv_end[i]);
 #pragma unroll
@@ -109,7 +111,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn64_kernel(const AArgs p) {
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 if (NT * g0 + i < p.nqt) kv = max(kv, p.tile_kv_end[NT * g0 + i]);
-            nheavy += (2 * kv >= kmax) ? 1 : 0;
+#ifndef PF_ATTN_LIGHT_NUM          // light = key range shorter than NUM / DEN of the longest (lab builds sweep it)
+#define PF_ATTN_LIGHT_NUM 1
+#define PF_ATTN_LIGHT_DEN 2
+#endif
+            nheavy += (PF_ATTN_LIGHT_DEN * kv >= PF_ATTN_LIGHT_NUM * kmax) ? 1 : 0;
         }
 #pragma unroll
         for (int o_ = 1; o_ < 64; o_ <<= 1) nheavy += __shfl_xor(nheavy, o_);
