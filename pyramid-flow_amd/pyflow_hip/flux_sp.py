@@ -293,7 +293,11 @@ class FluxEngineSP(FluxEngine):
             grp = self.group_text and fuse and n_img > 0 and n_txt > 0
 
             def groups(M_, N_, K_):
-                return grp and M_ > 0 and lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8
+                # the single-rank engine's rule (FluxEngine._groups_text): the persistent kernel as a whole-round launch (>= 192
+                # tiles) -- pf_gemm_which reports 8 for mid-size problems too, which the library serves by a K split through
+                # scratch and never as a grouped launch; those keep the text rows' own launch with their own scratch
+                return (grp and M_ > 0 and lib.pf_gemm_which(C.c_int(M_), C.c_int(B), C.c_int(N_), C.c_int(K_)) == 8 and
+                        -(-M_ // 256) * B * -(-N_ // 256) >= 192)
             g_kvq = groups(n_img, 3 * d, d)
             nq_t = blk["norm_added_q"] if blk["norm_added_q"] is not None else blk["norm_q"]
             nk_t = blk["norm_added_k"] if blk["norm_added_k"] is not None else blk["norm_k"]
