@@ -101,6 +101,9 @@ int main(int argc, char** argv) {
         {128, 2, D, 4 * D, -1, true, false, "text MLP down (128 rows, residual)"},
         {368, 2, D, 5 * D, -1, true, false, "proj_out at L = 368 (unit 0, stage 0)"},
         {608, 2, 7 * D, D, 3 * D, false, false, "K|V|Q|MLP at L = 608"},
+        // the d-wide projections WITHOUT their residual (what the residual loads + gate arithmetic of flavour 1 cost: compare 3 / 5)
+        {L, 2, D, D, -1, false, false, "attn out shape, plain (no residual)"},
+        {L, 2, D, 5 * D, -1, false, false, "proj_out shape, plain (no residual)"},
     };
     const char* only = getenv("GEMM_AB_SHAPES");          // e.g. "0,1,3"
     hipStream_t st;
