@@ -120,3 +120,25 @@ def test_conv_routing(so):
     d = _conv_desc(8, 256, 256, 128, 128)
     d.n_valid, d.Cg, d.Cout_pitch = 3, 8, 8       # three real filters into the 8-channel image buffer
     assert so.pf_conv3d_which(C.byref(d)) == -1
+
+
+def test_decode_conv_routes_of_the_headline_decode():
+    """config C3 / C5's tiled(256) / chunked decode, walked on the CPU through the library's own routing functions
+    (tools/vae_routes.py): the LDS-halo kernel carries the decode (>= 97 % of its FLOP), the narrow kernel serves conv_out, and what
+    is left for the implicit-GEMM kernels (the 1 x 1 x 1 shortcuts, the latent-resolution layers) stays below 3 % -- a routing change
+    that moves a full-resolution layer off the halo kernel shows up here without a GPU."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vae_routes", os.path.join(root, "tools", "vae_routes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tot = mod.decode_routes()
+    total = sum(tot.values())
+    assert 7.5e15 < total < 8.5e15, total                    # the decode's ~8 PFLOP of convolutions (DESIGN.md section 3)
+    assert tot.get("conv_halo128", 0.0) / total >= 0.97, tot
+    assert tot.get("conv_narrow", 0.0) > 0.0
+    rest = total - tot.get("conv_halo128", 0.0) - tot.get("conv_narrow", 0.0)
+    assert rest / total < 0.03, tot
+    from pyflow_hip import lib
+    assert lib.load().pf_version() == lib.ABI_VERSION         # the stub is gone again: the real library answers
