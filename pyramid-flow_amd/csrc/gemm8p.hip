@@ -501,11 +501,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const Args p) {
                             rbuf[f] = *(const u32x4_t*)(q.res + roff);
                         } else {
                             // one per-lane row pointer + a wave-uniform fragment stride: no per-fragment 64-bit
-                            // offsets kept alive across the epilogue; rows past M are not read at all
-                            // one per-lane row pointer + a wave-uniform fragment stride: no per-fragment 64-bit
                             // offsets kept alive across the epilogue; rows past M are not read at all.  (Round 6 tried these
-                            // loads in the coalesced memory layout + an inverse lane permutation, as the stores: the flavour
-                            // has no register left for it -- 12-92 bytes of scratch in every form tried.)
+                            // loads in the coalesced memory layout twice: with an inverse lane permutation of the pieces the
+                            // flavour has no register left -- 12-92 bytes of scratch in every form --; with the fp32 VALUES
+                            // permuted to meet them it fits (253 registers, same bits) and is no faster: what the flavour pays
+                            // is the two exposed load -> wait round trips, not the shape of the loads.
+                            // profiles/r06_gemm8p_small_variants_ab.log)
                             rbuf[f] = (u32x4_t){0u, 0u, 0u, 0u};
                             if (m < q.M) rbuf[f] = *(const u32x4_t*)(res_row + (long long)(16 * (f0 + f)) * p.ldr + n);
                         }
