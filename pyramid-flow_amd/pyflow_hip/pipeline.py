@@ -103,6 +103,8 @@ class PyramidDiTForVideoGeneration:
                                                                 stage_range=stage_range, gamma=scheduler_gamma)
         self.sequential_offload_enabled = False
         self.block_noise_fn = None          # (bs, ch, t, h, w) -> CPU fp32 tensor; None = vectorised global-RNG draw
+        self._noise_slots = {}              # shape -> two [pinned staging tensor, event] slots (_to_device_async)
+        self._mask_keys = {}                # id(mask) -> (mask, bytes) for the current generate() call (_mask_key)
         self._plans = {}
         self.plan_cache_size = 256
         self.timers = {}
@@ -175,10 +177,47 @@ class PyramidDiTForVideoGeneration:
         z = z.reshape(bs, ch, temp, height // 2, width // 2, 2, 2).permute(0, 1, 2, 3, 5, 4, 6)
         return z.reshape(bs, ch, temp, height, width)
 
+    def _to_device_async(self, z):
+        """a host fp32 tensor (the stage boundary's block noise) -> device WITHOUT blocking the host.  `.to(device)` from pageable
+        memory is a synchronous copy: it returns when the stream has drained, i.e. the host -- which runs a whole stage ahead of
+        the device (one graph launch per step) -- stopped at every stage boundary, and the device then idled for the copy plus the
+        host's way to the next forward: 2.2 + 0.7 ms x 62 boundaries of a 241-frame video (round 6: tools/gap_analysis.py on a
+        kernel trace of bench.py).  Here the values go through a pinned staging slot (two per shape, guarded by an event: a slot
+        is rewritten only after the copy that read it has executed) and an asynchronous copy on the current stream, ordered
+        behind the stage that is still running and in front of the re-noising kernel that consumes it.  Same draw, same values."""
+        if z.is_cuda:
+            return z.to(self._device, torch.float32).contiguous()
+        ring = self._noise_slots.setdefault(tuple(z.shape), [])
+        if len(ring) < 2:
+            slot = [torch.empty(tuple(z.shape), dtype=torch.float32).pin_memory(), None]
+            ring.append(slot)
+        else:
+            slot = ring.pop(0)
+            ring.append(slot)
+            if slot[1] is not None:
+                slot[1].synchronize()
+        slot[0].copy_(z)
+        out = torch.empty(tuple(z.shape), dtype=torch.float32, device=self._device)
+        out.copy_(slot[0], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[1] = ev
+        return out
+
+    def _mask_key(self, mask):
+        """bytes of a prompt mask, read back ONCE per mask tensor and generate() call (a device-resident mask -- the text encoders'
+        output -- costs a blocking device-to-host copy per (unit, stage) otherwise)"""
+        hit = self._mask_keys.get(id(mask))
+        if hit is not None and hit[0] is mask:
+            return hit[1]
+        key = mask.cpu().numpy().tobytes()
+        self._mask_keys[id(mask)] = (mask, key)
+        return key
+
     # ---- plan cache
     def _plan(self, shapes, mask):
         pair = bool(self.do_classifier_free_guidance)        # the rows of `mask` are one sample's [negative | positive] pair
-        key = (tuple(shapes), mask.cpu().numpy().tobytes(), pair)
+        key = (tuple(shapes), self._mask_key(mask), pair)
         p = self._plans.pop(key, None)
         if p is None:
             # LRU over a WHOLE schedule (the headline job has 93 (unit, stage) sequences, C2 / C4 48): the plan carries its
@@ -266,7 +305,7 @@ class PyramidDiTForVideoGeneration:
                 gamma = self.scheduler.config.gamma
                 alpha = 1 / (math.sqrt(1 + (1 / gamma)) * (1 - ori_sigma) + ori_sigma)
                 beta = alpha * (1 - ori_sigma) / math.sqrt(gamma)
-                noise = self.sample_block_noise(nb, C, 1, h, w).to(self._device, torch.float32).contiguous()
+                noise = self._to_device_async(self.sample_block_noise(nb, C, 1, h, w))
                 if self.sp is not None:          # rank-local RNG streams may differ: rank 0's draw is the one used
                     self.sp.broadcast(noise, 0)
                 for b in range(nb):
@@ -313,6 +352,7 @@ class PyramidDiTForVideoGeneration:
         assert (temp - 1) % self.frame_per_unit == 0, "The frames should be divided by frame_per unit"
         assert height % 64 == 0 and width % 64 == 0, "height/width must be multiples of 64 (8 VAE x 4 pyramid x 2 patch)"
         n_st = len(self.stages)
+        self._mask_keys = {}          # (a caller may refill a mask tensor in place between calls)
         if isinstance(num_inference_steps, int):
             num_inference_steps = [num_inference_steps] * n_st
         if isinstance(video_num_inference_steps, int):
@@ -459,6 +499,7 @@ class PyramidDiTForVideoGeneration:
         assert temp % self.frame_per_unit == 0, "The frames should be divided by frame_per unit"
         assert height % 64 == 0 and width % 64 == 0, "height/width must be multiples of 64 (8 VAE x 4 pyramid x 2 patch)"
         n_st = len(self.stages)
+        self._mask_keys = {}          # (a caller may refill a mask tensor in place between calls)
         if isinstance(num_inference_steps, int):
             num_inference_steps = [num_inference_steps] * n_st
         if prompt_embeds is None:
