@@ -104,6 +104,7 @@ class PyramidDiTForVideoGeneration:
         self.sequential_offload_enabled = False
         self.block_noise_fn = None          # (bs, ch, t, h, w) -> CPU fp32 tensor; None = vectorised global-RNG draw
         self._noise_slots = {}              # shape -> two [pinned staging tensor, event] slots (_to_device_async)
+        self._chol = {}                     # gamma -> closed-form Cholesky factor (numpy)
         self._mask_keys = {}                # id(mask) -> (mask, bytes) for the current generate() call (_mask_key)
         self._plans = {}
         self.plan_cache_size = 256
@@ -168,16 +169,36 @@ class PyramidDiTForVideoGeneration:
         gdev = generator.device if generator is not None else "cpu"
         return torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
 
+    def _block_noise_into(self, out):
+        """default draw, written into `out` (a contiguous CPU fp32 tensor [bs, ch, t, h, w], possibly pinned): ONE
+        torch.randn(N, 4) from the global generator (N = 2 x 2 blocks), block k's four values = L . eps_k laid out
+        `(b c t h w) (p q) -> b c t (h p) (w q)` (:697-703).  The 4 x 4 product and the rearrangement are written as eight
+        numpy multiply-adds on strided views: a 4-column matmul and a permuting copy of 60 k floats each start an OpenMP
+        region in torch, which costs 3-5 ms per stage boundary on a 64-core host -- more than a stage-0 forward of config C2
+        lasts on the device (tools/host_stage_boundary.py)."""
+        bs, ch, temp, height, width = out.shape
+        g = float(self.scheduler.config.gamma)
+        L = self._chol.get(g)
+        if L is None:
+            L = self._chol[g] = block_noise_cholesky(g).numpy().copy()
+        n = bs * ch * temp * (height // 2) * (width // 2)
+        eps = torch.randn(n, 4).numpy().reshape(bs, ch, temp, height // 2, width // 2, 4)
+        o = out.numpy().reshape(bs, ch, temp, height // 2, 2, width // 2, 2)
+        for i in range(4):                          # output position (p, q) = (i // 2, i % 2) of every block; L is lower triangular
+            dst = o[:, :, :, :, i // 2, :, i % 2]
+            np.multiply(eps[..., 0], L[i, 0], out=dst)
+            for k in range(1, i + 1):
+                dst += eps[..., k] * L[i, k]
+        return out
+
     def sample_block_noise(self, bs, ch, temp, height, width):
         if self.block_noise_fn is not None:
             return self.block_noise_fn(bs, ch, temp, height, width)
-        L = block_noise_cholesky(self.scheduler.config.gamma)
-        n = bs * ch * temp * (height // 2) * (width // 2)
-        z = torch.randn(n, 4) @ L.T
-        z = z.reshape(bs, ch, temp, height // 2, width // 2, 2, 2).permute(0, 1, 2, 3, 5, 4, 6)
-        return z.reshape(bs, ch, temp, height, width)
+        if not hasattr(self, "_chol"):
+            self._chol = {}
+        return self._block_noise_into(torch.empty(bs, ch, temp, height, width, dtype=torch.float32))
 
-    def _to_device_async(self, z):
+    def _to_device_async(self, z, shape=None):
         """a host fp32 tensor (the stage boundary's block noise) -> device WITHOUT blocking the host.  `.to(device)` from pageable
         memory is a synchronous copy: it returns when the stream has drained, i.e. the host -- which runs a whole stage ahead of
         the device (one graph launch per step) -- stopped at every stage boundary, and the device then idled for the copy plus the
@@ -185,19 +206,23 @@ class PyramidDiTForVideoGeneration:
         kernel trace of bench.py).  Here the values go through a pinned staging slot (two per shape, guarded by an event: a slot
         is rewritten only after the copy that read it has executed) and an asynchronous copy on the current stream, ordered
         behind the stage that is still running and in front of the re-noising kernel that consumes it.  Same draw, same values."""
-        if z.is_cuda:
+        if z is not None and z.is_cuda:
             return z.to(self._device, torch.float32).contiguous()
-        ring = self._noise_slots.setdefault(tuple(z.shape), [])
+        shape = tuple(shape) if z is None else tuple(z.shape)
+        ring = self._noise_slots.setdefault(shape, [])
         if len(ring) < 2:
-            slot = [torch.empty(tuple(z.shape), dtype=torch.float32).pin_memory(), None]
+            slot = [torch.empty(shape, dtype=torch.float32).pin_memory(), None]
             ring.append(slot)
         else:
             slot = ring.pop(0)
             ring.append(slot)
             if slot[1] is not None:
                 slot[1].synchronize()
-        slot[0].copy_(z)
-        out = torch.empty(tuple(z.shape), dtype=torch.float32, device=self._device)
+        if z is None:
+            self._block_noise_into(slot[0])          # the default draw goes straight into the staging slot
+        else:
+            slot[0].copy_(z)
+        out = torch.empty(shape, dtype=torch.float32, device=self._device)
         out.copy_(slot[0], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -305,7 +330,10 @@ class PyramidDiTForVideoGeneration:
                 gamma = self.scheduler.config.gamma
                 alpha = 1 / (math.sqrt(1 + (1 / gamma)) * (1 - ori_sigma) + ori_sigma)
                 beta = alpha * (1 - ori_sigma) / math.sqrt(gamma)
-                noise = self._to_device_async(self.sample_block_noise(nb, C, 1, h, w))
+                if self.block_noise_fn is None:
+                    noise = self._to_device_async(None, (nb, C, 1, h, w))          # drawn into the pinned staging slot
+                else:
+                    noise = self._to_device_async(self.sample_block_noise(nb, C, 1, h, w))
                 if self.sp is not None:          # rank-local RNG streams may differ: rank 0's draw is the one used
                     self.sp.broadcast(noise, 0)
                 for b in range(nb):

@@ -56,3 +56,19 @@ for k, (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:16]:
 print("largest gaps (ms): between <kernel before> and <kernel after>")
 for g, a, b in gaps[:25]:
     print(f"   {g / 1e6:8.3f}  {a[:60]:60s} -> {b[:60]}")
+# ---- the decode that follows the loop: from the last Euler step to the last kernel of the trace (lanes overlap: union of intervals)
+tail = rows[last + 1:]
+if tail:
+    d0, cur_end, busy2, gaps2, prev = rows[last][1], rows[last][1], 0, [], rows[last][2]
+    for s_, e_, n_ in tail:
+        if s_ > cur_end:
+            gaps2.append((s_ - cur_end, prev, n_))
+        if e_ > cur_end:
+            busy2 += e_ - max(s_, cur_end)
+            cur_end = e_
+            prev = n_
+    span2 = cur_end - d0
+    print(f"after the loop (decode + frame copies): {span2 / 1e9:.3f} s, {len(tail)} kernels, busy {busy2 / 1e9:.3f} s, idle {(span2 - busy2) / 1e9:.3f} s = {100 * (span2 - busy2) / max(span2, 1):.2f} %")
+    gaps2.sort(reverse=True)
+    for g, a, b in gaps2[:12]:
+        print(f"   {g / 1e6:8.3f}  {a[:60]:60s} -> {b[:60]}")
