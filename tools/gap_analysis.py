@@ -53,8 +53,17 @@ for g, a, b in gaps:
 print("gaps >= 0.1 ms by (kernel before -> kernel after): count, total ms")
 for k, (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:16]:
     print(f"   {n:5d} {t / 1e6:9.1f}   {k[0]:34s} -> {k[1]}")
+pairs2 = collections.defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    if 10000 <= g < 100000:
+        k = (a.replace("(anonymous namespace)::", "").replace("void ", "")[:34], b.replace("(anonymous namespace)::", "").replace("void ", "")[:34])
+        pairs2[k][0] += 1
+        pairs2[k][1] += g
+print("gaps of 10-100 us by (kernel before -> kernel after): count, total ms, mean us")
+for k, (n, t) in sorted(pairs2.items(), key=lambda kv: -kv[1][1])[:14]:
+    print(f"   {n:5d} {t / 1e6:9.1f} {t / n / 1e3:7.1f}   {k[0]:34s} -> {k[1]}")
 print("largest gaps (ms): between <kernel before> and <kernel after>")
-for g, a, b in gaps[:25]:
+for g, a, b in gaps[:8]:
     print(f"   {g / 1e6:8.3f}  {a[:60]:60s} -> {b[:60]}")
 # ---- the decode that follows the loop: from the last Euler step to the last kernel of the trace (lanes overlap: union of intervals)
 tail = rows[last + 1:]
