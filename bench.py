@@ -348,7 +348,11 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic in the run (N = 1, headline "
                          "workload); the committed profile is replayed instead and the line says so")
-    ap.add_argument("--profile-period", type=int, default=7)
+    ap.add_argument("--profile-period", type=int, default=21,
+                    help="every N-th DiT forward of the timed region runs eagerly with a HIP-event pair around each launch (the "
+                         "roofline sample).  21 is coprime with the schedule's 10 / 20 steps per stage, so the sample walks every stage "
+                         "and length; the sampled forwards cost the step ~0.1 s at N = 7 (same-box A/B: 43.70 / 43.67 s vs 43.60 s with "
+                         "no sample, 43.58 s at N = 28: profiles/r06_bench_sampling_period_ab.log)")
     ap.add_argument("--group-text", default="auto", choices=["auto", "on", "off"],
                     help="double blocks: the text stream's GEMMs inside the image stream's persistent launches (pf_gemm_desc.A2 ..., "
                          "FluxEngine.group_text) -- auto = the engine's default (A/B switch)")
