@@ -68,3 +68,22 @@ def test_injected_block_noise_fn_is_used():
     p = _pipe()
     p.block_noise_fn = lambda *s: torch.full(s, 3.0)
     assert torch.equal(p.sample_block_noise(1, 2, 1, 4, 4), torch.full((1, 2, 1, 4, 4), 3.0))
+
+
+def test_default_draw_is_the_matrix_product_it_replaces():
+    """round 6: the draw is written as numpy multiply-adds on strided views (two OpenMP regions per stage boundary were the
+    host's longest pause); it must stay the product it replaces -- ONE randn(N, 4) from the global generator, times L^T, laid out
+    `(b c t h w) (p q) -> b c t (h p) (w q)` -- to fp32 rounding"""
+    bs, ch, t, h, w = 2, 16, 1, 24, 40
+    torch.manual_seed(11)
+    z = _pipe().sample_block_noise(bs, ch, t, h, w)
+    torch.manual_seed(11)
+    eps = torch.randn(bs * ch * t * (h // 2) * (w // 2), 4)
+    L = block_noise_cholesky(1 / 3)
+    ref = (eps.double() @ L.double().T).reshape(bs, ch, t, h // 2, w // 2, 2, 2).permute(0, 1, 2, 3, 5, 4, 6).reshape(bs, ch, t, h, w)
+    assert z.is_contiguous() and (z.double() - ref).abs().max() < 1e-6
+    # and the next draw continues the same global stream (nothing else consumed the generator)
+    a = torch.randn(3)
+    torch.manual_seed(11)
+    torch.randn(bs * ch * t * (h // 2) * (w // 2), 4)
+    assert torch.equal(a, torch.randn(3))
