@@ -161,3 +161,26 @@ def test_generate_prompt_batch_vs_reference_fixture():
     T = 1 + 8 * (g["temp"] - 1)
     assert fr.shape == (2 * T, g["height"], g["width"], 3) and fr.dtype == torch.uint8
     assert not torch.equal(fr[:T], fr[T:])
+
+
+def test_block_noise_upload_slots_survive_reuse_and_the_default_draw_is_the_host_draw():
+    """round 6: the stage boundary's block noise goes to the device through two pinned staging slots per shape and an asynchronous
+    copy (the host no longer stops at every stage boundary).  (i) Five uploads of one shape queued behind a long-running kernel:
+    a slot is rewritten only after the copy that read it has executed, so every device tensor holds ITS values; (ii) the default
+    draw written straight into the staging slot is the draw sample_block_noise() returns for the same global-generator state."""
+    g = torch.load(GOLD)
+    pipe, _, _ = _pipe(g)
+    big = torch.randn(8192, 8192, device="cuda")
+    srcs = [torch.randn(1, 16, 1, 24, 40) for _ in range(5)]
+    for _ in range(6):
+        big = big @ big.t() * 1e-4                      # keeps the stream busy while the host runs ahead
+    outs = [pipe._to_device_async(s) for s in srcs]
+    torch.cuda.synchronize()
+    for s, o in zip(srcs, outs):
+        assert torch.equal(o.cpu(), s)
+    pipe.block_noise_fn = None
+    torch.manual_seed(5)
+    want = pipe.sample_block_noise(1, 16, 1, 24, 40)
+    torch.manual_seed(5)
+    got = pipe._to_device_async(None, (1, 16, 1, 24, 40))
+    assert torch.equal(got.cpu(), want)
